@@ -1,0 +1,433 @@
+// BN254 field and curve arithmetic for gfx950 (and for the host side of libspp).
+//
+// 254-bit prime fields in Montgomery form on 8 x 32-bit limbs: the natural word of the CDNA4 VALU
+// (v_mad_u64_u32 does 32x32+64 -> 64 in one instruction; there is no 64x64 multiplier). Everything is
+// written so that, after full unrolling, limbs live in VGPRs and the modulus limbs fold to literals.
+// The same code compiles for the host (g++) -- used there only for one-time work (circuit constants,
+// setup scalars); the proving hot path runs it on the GPU.
+//
+// Replaces: the gnark-crypto fr/fp/G1/G2 arithmetic that `sunspot prove`
+// (client/proof.helper.ts:64 of the reference) executes on the CPU.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include "bn254_consts.hpp"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SPP_HD __host__ __device__ __forceinline__
+#define SPP_UNROLL _Pragma("unroll")
+#else
+#define SPP_HD inline
+#define SPP_UNROLL
+#endif
+
+namespace spp {
+
+// --------------------------------------------------------------------------------------------------
+// Fp<Params>: element of GF(p) in Montgomery form (value * 2^256 mod p), always fully reduced (< p).
+// --------------------------------------------------------------------------------------------------
+template <class Pm>
+struct Fp {
+  uint32_t l[8];
+
+  static SPP_HD Fp zero() {
+    Fp r;
+    SPP_UNROLL for (int i = 0; i < 8; i++) r.l[i] = 0;
+    return r;
+  }
+  static SPP_HD Fp one() {
+    Fp r;
+    SPP_UNROLL for (int i = 0; i < 8; i++) r.l[i] = Pm::ONE(i);
+    return r;
+  }
+  static SPP_HD Fp r2() {
+    Fp r;
+    SPP_UNROLL for (int i = 0; i < 8; i++) r.l[i] = Pm::R2(i);
+    return r;
+  }
+  static SPP_HD Fp r3() {
+    Fp r;
+    SPP_UNROLL for (int i = 0; i < 8; i++) r.l[i] = Pm::R3(i);
+    return r;
+  }
+  SPP_HD bool is_zero() const {
+    uint32_t o = 0;
+    SPP_UNROLL for (int i = 0; i < 8; i++) o |= l[i];
+    return o == 0;
+  }
+  SPP_HD bool operator==(const Fp& b) const {
+    uint32_t o = 0;
+    SPP_UNROLL for (int i = 0; i < 8; i++) o |= l[i] ^ b.l[i];
+    return o == 0;
+  }
+  SPP_HD bool operator!=(const Fp& b) const { return !(*this == b); }
+
+  // raw limbs >= modulus ?
+  static SPP_HD bool geq_mod(const uint32_t* a) {
+    // compute a - p, look at the borrow
+    uint64_t br = 0;
+    SPP_UNROLL for (int i = 0; i < 8; i++) {
+      uint64_t d = (uint64_t)a[i] - Pm::MOD(i) - br;
+      br = (d >> 63) & 1;
+    }
+    return br == 0;
+  }
+  // r = a - p if a >= p (a < 2p)
+  static SPP_HD void cond_sub(uint32_t* a) {
+    uint32_t t[8];
+    uint64_t br = 0;
+    SPP_UNROLL for (int i = 0; i < 8; i++) {
+      uint64_t d = (uint64_t)a[i] - Pm::MOD(i) - br;
+      t[i] = (uint32_t)d;
+      br = (d >> 63) & 1;
+    }
+    if (br == 0) {
+      SPP_UNROLL for (int i = 0; i < 8; i++) a[i] = t[i];
+    }
+  }
+
+  friend SPP_HD Fp operator+(const Fp& a, const Fp& b) {
+    Fp r;
+    uint64_t c = 0;
+    SPP_UNROLL for (int i = 0; i < 8; i++) {
+      c += (uint64_t)a.l[i] + b.l[i];
+      r.l[i] = (uint32_t)c;
+      c >>= 32;
+    }
+    // p < 2^254 so a+b < 2^255: no carry out of limb 7
+    cond_sub(r.l);
+    return r;
+  }
+  friend SPP_HD Fp operator-(const Fp& a, const Fp& b) {
+    Fp r;
+    uint64_t br = 0;
+    SPP_UNROLL for (int i = 0; i < 8; i++) {
+      uint64_t d = (uint64_t)a.l[i] - b.l[i] - br;
+      r.l[i] = (uint32_t)d;
+      br = (d >> 63) & 1;
+    }
+    if (br) {
+      uint64_t c = 0;
+      SPP_UNROLL for (int i = 0; i < 8; i++) {
+        c += (uint64_t)r.l[i] + Pm::MOD(i);
+        r.l[i] = (uint32_t)c;
+        c >>= 32;
+      }
+    }
+    return r;
+  }
+  SPP_HD Fp neg() const {
+    if (is_zero()) return *this;
+    Fp r;
+    uint64_t br = 0;
+    SPP_UNROLL for (int i = 0; i < 8; i++) {
+      uint64_t d = (uint64_t)Pm::MOD(i) - l[i] - br;
+      r.l[i] = (uint32_t)d;
+      br = (d >> 63) & 1;
+    }
+    return r;
+  }
+  SPP_HD Fp dbl() const { return *this + *this; }
+
+  // Montgomery product, CIOS fused with the reduction (valid because p < 2^254: no extra carry word).
+  friend SPP_HD Fp operator*(const Fp& a, const Fp& b) {
+    uint32_t t[8];
+    SPP_UNROLL for (int i = 0; i < 8; i++) t[i] = 0;
+    SPP_UNROLL for (int i = 0; i < 8; i++) {
+      const uint32_t bi = b.l[i];
+      uint64_t A = (uint64_t)a.l[0] * bi + t[0];
+      const uint32_t m = (uint32_t)A * Pm::INV32;
+      uint64_t C = (uint64_t)m * Pm::MOD(0) + (uint32_t)A;
+      A >>= 32;
+      C >>= 32;
+      SPP_UNROLL for (int j = 1; j < 8; j++) {
+        A += (uint64_t)a.l[j] * bi + t[j];
+        C += (uint64_t)m * Pm::MOD(j) + (uint32_t)A;
+        t[j - 1] = (uint32_t)C;
+        A >>= 32;
+        C >>= 32;
+      }
+      t[7] = (uint32_t)(A + C);
+    }
+    Fp r;
+    SPP_UNROLL for (int i = 0; i < 8; i++) r.l[i] = t[i];
+    cond_sub(r.l);
+    return r;
+  }
+  SPP_HD Fp sqr() const { return *this * *this; }
+
+  // multiply by a small unsigned constant (k < 2^16) via double-and-add on the bits of k
+  SPP_HD Fp mul_small(uint32_t k) const {
+    Fp acc = zero();
+    Fp base = *this;
+    while (k) {
+      if (k & 1) acc = acc + base;
+      base = base.dbl();
+      k >>= 1;
+    }
+    return acc;
+  }
+
+  // canonical (non-Montgomery) limbs
+  SPP_HD void to_canonical(uint32_t out[8]) const {
+    Fp o;
+    SPP_UNROLL for (int i = 0; i < 8; i++) o.l[i] = (i == 0);
+    Fp c = *this * o;  // a*R * 1 / R = a
+    SPP_UNROLL for (int i = 0; i < 8; i++) out[i] = c.l[i];
+  }
+  // from canonical limbs (must be < p)
+  static SPP_HD Fp from_canonical(const uint32_t in[8]) {
+    Fp a;
+    SPP_UNROLL for (int i = 0; i < 8; i++) a.l[i] = in[i];
+    return a * r2();
+  }
+  // from arbitrary 256-bit limbs (reduced mod p; input < 2^256 < 6p)
+  static SPP_HD Fp from_u256(const uint32_t in[8]) {
+    Fp a;
+    SPP_UNROLL for (int i = 0; i < 8; i++) a.l[i] = in[i];
+    for (int k = 0; k < 6; k++) cond_sub(a.l);  // 2^256 < 6p
+    return a * r2();
+  }
+  static SPP_HD Fp from_u64(uint64_t v) {
+    uint32_t c[8];
+    SPP_UNROLL for (int i = 0; i < 8; i++) c[i] = 0;
+    c[0] = (uint32_t)v;
+    c[1] = (uint32_t)(v >> 32);
+    return from_canonical(c);
+  }
+  // 32-byte big-endian canonical
+  SPP_HD void to_bytes_be(uint8_t out[32]) const {
+    uint32_t c[8];
+    to_canonical(c);
+    SPP_UNROLL for (int i = 0; i < 8; i++) {
+      uint32_t w = c[7 - i];
+      out[4 * i + 0] = (uint8_t)(w >> 24);
+      out[4 * i + 1] = (uint8_t)(w >> 16);
+      out[4 * i + 2] = (uint8_t)(w >> 8);
+      out[4 * i + 3] = (uint8_t)w;
+    }
+  }
+  static SPP_HD Fp from_bytes_be(const uint8_t in[32]) {
+    uint32_t c[8];
+    SPP_UNROLL for (int i = 0; i < 8; i++) {
+      c[7 - i] = ((uint32_t)in[4 * i] << 24) | ((uint32_t)in[4 * i + 1] << 16) | ((uint32_t)in[4 * i + 2] << 8) |
+                 (uint32_t)in[4 * i + 3];
+    }
+    return from_u256(c);
+  }
+
+  // a^(p-2) (Fermat); uniform control flow: the exponent is a compile-time constant
+  SPP_HD Fp inv() const {
+    Fp result = one();
+    Fp base = *this;
+    for (int w = 0; w < 8; w++) {
+      uint32_t e = Pm::MODM2(w);
+      for (int b = 0; b < 32; b++) {
+        if ((e >> b) & 1) result = result * base;
+        base = base.sqr();
+      }
+    }
+    return result;
+  }
+  SPP_HD Fp pow_u64(uint64_t e) const {
+    Fp result = one();
+    Fp base = *this;
+    while (e) {
+      if (e & 1) result = result * base;
+      base = base.sqr();
+      e >>= 1;
+    }
+    return result;
+  }
+};
+
+using Fr = Fp<FrParams>;
+using Fq = Fp<FqParams>;
+
+// canonical limbs > (p-1)/2 ?
+template <class Pm>
+SPP_HD bool canonical_gt_half(const uint32_t c[8]) {
+  // HALF - c < 0  <=>  c > HALF
+  uint64_t br = 0;
+  SPP_UNROLL for (int i = 0; i < 8; i++) {
+    uint64_t d = (uint64_t)Pm::HALF(i) - c[i] - br;
+    br = (d >> 63) & 1;
+  }
+  return br != 0;
+}
+// out = p - c  (c canonical, nonzero)
+template <class Pm>
+SPP_HD void canonical_negate(const uint32_t c[8], uint32_t out[8]) {
+  uint64_t br = 0;
+  SPP_UNROLL for (int i = 0; i < 8; i++) {
+    uint64_t d = (uint64_t)Pm::MOD(i) - c[i] - br;
+    out[i] = (uint32_t)d;
+    br = (d >> 63) & 1;
+  }
+}
+
+// --------------------------------------------------------------------------------------------------
+// Fq2 = Fq[u]/(u^2+1)
+// --------------------------------------------------------------------------------------------------
+struct Fq2 {
+  Fq c0, c1;
+  static SPP_HD Fq2 zero() { return {Fq::zero(), Fq::zero()}; }
+  static SPP_HD Fq2 one() { return {Fq::one(), Fq::zero()}; }
+  SPP_HD bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+  SPP_HD bool operator==(const Fq2& b) const { return c0 == b.c0 && c1 == b.c1; }
+  SPP_HD bool operator!=(const Fq2& b) const { return !(*this == b); }
+  friend SPP_HD Fq2 operator+(const Fq2& a, const Fq2& b) { return {a.c0 + b.c0, a.c1 + b.c1}; }
+  friend SPP_HD Fq2 operator-(const Fq2& a, const Fq2& b) { return {a.c0 - b.c0, a.c1 - b.c1}; }
+  SPP_HD Fq2 neg() const { return {c0.neg(), c1.neg()}; }
+  SPP_HD Fq2 dbl() const { return {c0.dbl(), c1.dbl()}; }
+  friend SPP_HD Fq2 operator*(const Fq2& a, const Fq2& b) {
+    Fq v0 = a.c0 * b.c0;
+    Fq v1 = a.c1 * b.c1;
+    Fq s = (a.c0 + a.c1) * (b.c0 + b.c1);
+    return {v0 - v1, s - v0 - v1};
+  }
+  SPP_HD Fq2 sqr() const {
+    Fq t = c0 * c1;
+    return {(c0 + c1) * (c0 - c1), t.dbl()};
+  }
+  SPP_HD Fq2 inv() const {
+    Fq d = (c0.sqr() + c1.sqr()).inv();
+    return {c0 * d, (c1 * d).neg()};
+  }
+  SPP_HD Fq2 mul_small(uint32_t k) const { return {c0.mul_small(k), c1.mul_small(k)}; }
+};
+
+// --------------------------------------------------------------------------------------------------
+// Short-Weierstrass curves y^2 = x^3 + b (a = 0) over F: G1 (F=Fq), G2 (F=Fq2), Grumpkin (F=Fr).
+// Affine points (infinity encoded as x=y=0, never on these curves) and extended-Jacobian "XYZZ"
+// accumulators: x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2; infinity <=> ZZ = 0. Mixed addition is 8M+2S.
+// --------------------------------------------------------------------------------------------------
+template <class F>
+struct Affine {
+  F x, y;
+  static SPP_HD Affine infinity() { return {F::zero(), F::zero()}; }
+  SPP_HD bool is_inf() const { return x.is_zero() && y.is_zero(); }
+  SPP_HD Affine neg() const { return {x, y.neg()}; }
+};
+
+template <class F>
+struct XYZZ {
+  F X, Y, ZZ, ZZZ;
+  static SPP_HD XYZZ infinity() { return {F::one(), F::one(), F::zero(), F::zero()}; }
+  SPP_HD bool is_inf() const { return ZZ.is_zero(); }
+  static SPP_HD XYZZ from_affine(const Affine<F>& p) {
+    if (p.is_inf()) return infinity();
+    return {p.x, p.y, F::one(), F::one()};
+  }
+  SPP_HD XYZZ neg() const { return {X, Y.neg(), ZZ, ZZZ}; }
+
+  // this = 2*this
+  SPP_HD void dbl_inplace() {
+    if (is_inf()) return;
+    F U = Y.dbl();
+    F V = U.sqr();
+    F W = U * V;
+    F S = X * V;
+    F X2 = X.sqr();
+    F M = X2.dbl() + X2;
+    F X3 = M.sqr() - S.dbl();
+    F Y3 = M * (S - X3) - W * Y;
+    ZZ = V * ZZ;
+    ZZZ = W * ZZZ;
+    X = X3;
+    Y = Y3;
+  }
+  // this += p (affine, not infinity unless flagged by caller)
+  SPP_HD void madd(const Affine<F>& p) {
+    if (p.is_inf()) return;
+    if (is_inf()) {
+      X = p.x;
+      Y = p.y;
+      ZZ = F::one();
+      ZZZ = F::one();
+      return;
+    }
+    F U2 = p.x * ZZ;
+    F S2 = p.y * ZZZ;
+    F Pp = U2 - X;
+    F Rr = S2 - Y;
+    if (Pp.is_zero()) {
+      if (Rr.is_zero()) {
+        dbl_inplace();
+      } else {
+        *this = infinity();
+      }
+      return;
+    }
+    F PP = Pp.sqr();
+    F PPP = Pp * PP;
+    F Q = X * PP;
+    F X3 = Rr.sqr() - PPP - Q.dbl();
+    F Y3 = Rr * (Q - X3) - Y * PPP;
+    ZZ = ZZ * PP;
+    ZZZ = ZZZ * PPP;
+    X = X3;
+    Y = Y3;
+  }
+  // this += q
+  SPP_HD void add(const XYZZ& q) {
+    if (q.is_inf()) return;
+    if (is_inf()) {
+      *this = q;
+      return;
+    }
+    F U1 = X * q.ZZ;
+    F U2 = q.X * ZZ;
+    F S1 = Y * q.ZZZ;
+    F S2 = q.Y * ZZZ;
+    F Pp = U2 - U1;
+    F Rr = S2 - S1;
+    if (Pp.is_zero()) {
+      if (Rr.is_zero()) {
+        dbl_inplace();
+      } else {
+        *this = infinity();
+      }
+      return;
+    }
+    F PP = Pp.sqr();
+    F PPP = Pp * PP;
+    F Q = U1 * PP;
+    F X3 = Rr.sqr() - PPP - Q.dbl();
+    F Y3 = Rr * (Q - X3) - S1 * PPP;
+    ZZ = ZZ * q.ZZ * PP;
+    ZZZ = ZZZ * q.ZZZ * PPP;
+    X = X3;
+    Y = Y3;
+  }
+  SPP_HD Affine<F> to_affine() const {
+    if (is_inf()) return Affine<F>::infinity();
+    F i = (ZZ * ZZZ).inv();
+    F izz = i * ZZZ;   // 1/ZZ
+    F izzz = i * ZZ;   // 1/ZZZ
+    return {X * izz, Y * izzz};
+  }
+};
+
+using G1Affine = Affine<Fq>;
+using G2Affine = Affine<Fq2>;
+using G1XYZZ = XYZZ<Fq>;
+using G2XYZZ = XYZZ<Fq2>;
+using GkAffine = Affine<Fr>;   // Grumpkin: coordinates in Fr
+using GkXYZZ = XYZZ<Fr>;
+
+// variable-base scalar multiplication, scalar as 8 canonical limbs (MSB-first double-and-add)
+template <class F>
+SPP_HD XYZZ<F> scalar_mul(const Affine<F>& p, const uint32_t k[8]) {
+  XYZZ<F> acc = XYZZ<F>::infinity();
+  for (int w = 7; w >= 0; w--) {
+    for (int b = 31; b >= 0; b--) {
+      acc.dbl_inplace();
+      if ((k[w] >> b) & 1) acc.madd(p);
+    }
+  }
+  return acc;
+}
+
+}  // namespace spp
