@@ -1,0 +1,118 @@
+/* libspp -- C ABI of the MI355X-native Groth16 prover for the shielded-pool circuits.
+ *
+ * Drop-in boundary for the proving path of Ham3798/shielded-pool-pinocchio-solana. Each entry point
+ * names the reference interface it replaces (paths relative to the reference tree):
+ *
+ *   spp_prove_withdraw        client/proof.helper.ts:28-72  generateProof(): the two child processes
+ *                             `nargo execute` (:55) + `sunspot prove` (:64) and the .proof/.pw reads (:68-69)
+ *   spp_prove_batch           client/payroll-demo.ts:326-352 (Promise.all over generateProof) and
+ *                             audit_circuit/prove_audit.sh:74-99 / scripts/generate_audit.py:668-685
+ *   spp_setup                 `sunspot setup <ccs>`   noir_circuit/prove_linux.sh:72-79, generate_audit.py:670-677
+ *   spp_circuit_build         `sunspot compile <acir>` noir_circuit/prove_linux.sh:66-70, generate_audit.py:659-665
+ *   spp_rlwe_witness_batch    scripts/generate_audit.py:507-584 (encrypt + quotient witnesses + packing),
+ *                             demo-frontend/app/lib/rlwe.ts:157-247
+ *   spp_poseidon_*            client/merkle.ts:22-38,119-140,165-221 (circomlibjs Poseidon, Merkle tree)
+ *   spp_grumpkin_keygen_batch client/merkle.ts:98-113 generateIdentityKeypair
+ *   spp_msm_g1 / spp_ntt_fr   micro-benchmark entry points (BASELINE.json configs[4]); no reference equivalent
+ *
+ * Conventions: field elements cross the boundary as 32-byte big-endian canonical integers (the encoding
+ * of the reference's .pw files, shielded_pool_program/src/instructions/withdraw.rs:74-90); points as
+ * gnark raw uncompressed bytes (64 B G1, 128 B G2). The caller owns every buffer it passes; the library
+ * owns device memory inside spp_circuit. All functions return 0 on success or a negative SPP_ERR_* code,
+ * with a thread-local message available from spp_last_error(). Calls on one spp_ctx are serialised.
+ * There is no CPU fallback: without a HIP device spp_init fails with SPP_ERR_NO_DEVICE.
+ */
+#ifndef SPP_H
+#define SPP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPP_OK 0
+#define SPP_ERR_BAD_INPUT (-1)
+#define SPP_ERR_NO_DEVICE (-2)
+#define SPP_ERR_IO (-3)
+#define SPP_ERR_UNSAT (-4)       /* the inputs do not satisfy the circuit (proof refused before the MSMs) */
+#define SPP_ERR_HIP (-5)
+#define SPP_ERR_NOT_IMPLEMENTED (-6)
+#define SPP_ERR_FORMAT (-7)
+
+#define SPP_CIRCUIT_WITHDRAW 1   /* noir_circuit/src/main.nr */
+#define SPP_CIRCUIT_AUDIT 2      /* audit_circuit (scripts/generate_audit.py:246-465) */
+
+#define SPP_PROOF_LEN 388        /* withdraw.rs:13, submit_audit.rs:18 */
+#define SPP_WITHDRAW_PW_LEN 172  /* withdraw.rs:14-16 */
+#define SPP_AUDIT_PW_LEN 76      /* submit_audit.rs:19-21 */
+#define SPP_TREE_DEPTH 16        /* noir_circuit/src/main.nr:5 */
+
+typedef struct spp_ctx spp_ctx;
+typedef struct spp_circuit spp_circuit;
+
+/* Inputs of the withdraw circuit, field order of ShieldedPoolInputs (client/proof.helper.ts:6-21). */
+typedef struct {
+  uint8_t root[32], nullifier[32], recipient[32];
+  uint64_t amount;
+  uint8_t wa_commitment[32];
+  uint8_t secret_key[32], owner_x[32], owner_y[32], randomness[32];
+  uint64_t index;
+  uint8_t siblings[SPP_TREE_DEPTH][32];
+} spp_withdraw_inputs;
+
+const char* spp_last_error(void);
+const char* spp_version(void);
+
+/* ---- host-only: circuit construction (no GPU needed) ---- */
+/* Writes the R1CS + solver program container ("SPPC"). aux: for SPP_CIRCUIT_AUDIT the RLWE public key as
+ * 2048 uint32 (a[1024] then b[1024], demo-frontend/public/rlwe/rlwe_pk.json); NULL for withdraw.
+ * Prints nothing; *n_constraints (optional) receives the constraint count (`nbConstraints=` of sunspot compile). */
+int spp_circuit_build(int circuit_id, const uint32_t* aux, const char* out_path, uint32_t* n_constraints);
+
+/* ---- device context ---- */
+int spp_init(int device, spp_ctx** out);
+void spp_free_ctx(spp_ctx* ctx);
+
+/* Deterministic trusted setup on the GPU from a 32-byte seed: writes pk ("SPPK") and vk (gnark raw layout). */
+int spp_setup(spp_ctx* ctx, const char* circuit_path, const uint8_t seed[32], const char* pk_path, const char* vk_path);
+
+/* Loads R1CS + proving key, builds the window tables (window_bits in [4,16]; 0 = default 10) in HBM. */
+int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const char* pk_path, int window_bits, spp_circuit** out);
+void spp_free_circuit(spp_circuit* c);
+/* info[0..7] = id, n_public (without the constant), n_secret, n_wires, n_constraints, domain_log, n_inputs, window_bits */
+int spp_circuit_info(const spp_circuit* c, uint32_t info[8]);
+/* exact bytes of HBM held by the window tables */
+uint64_t spp_circuit_table_bytes(const spp_circuit* c);
+
+/* ---- proving ---- */
+/* Generic batch: inputs = count * n_inputs * 32 B (public then secret, big-endian), rs = count * 64 B blinding
+ * (r || s, reduced mod r; NULL = OS randomness). Outputs: proofs count*388, pws count*(12+32*n_public),
+ * status[count] (0 ok, SPP_ERR_UNSAT). Returns 0 if every proof was produced, else the first error. */
+int spp_prove_batch(spp_circuit* c, size_t count, const uint8_t* inputs, const uint8_t* rs, uint8_t* proofs, uint8_t* pws,
+                    int32_t* status);
+/* Same with every buffer already resident in HBM (device pointers); asynchronous on the circuit's stream
+ * until spp_sync(). d_status: uint32 per proof, nonzero = unsatisfied. */
+int spp_prove_batch_device(spp_circuit* c, size_t count, const void* d_inputs, const void* d_rs, void* d_proofs, void* d_pws,
+                           void* d_status);
+int spp_sync(spp_circuit* c);
+/* per-stage device time of the last spp_prove_batch_device call, milliseconds:
+ * [0] witness solve (+commitment), [1] matrix eval, [2] NTT/QAP, [3] MSM G1, [4] MSM G2, [5] assembly, [6] total;
+ * [7] = average duration of one k_msm_fixed<G1> launch (the dominant kernel), [8] = number of such launches */
+int spp_last_timings(spp_circuit* c, float ms[9]);
+
+int spp_prove_withdraw(spp_circuit* c, const spp_withdraw_inputs* in, const uint8_t rs_seed[64], uint8_t proof[SPP_PROOF_LEN],
+                       uint8_t pw[SPP_WITHDRAW_PW_LEN]);
+
+/* debug / parity: full witness of proof 0 of the last batch, n_wires * 32 B big-endian */
+int spp_debug_witness(spp_circuit* c, uint8_t* out, size_t n_wires);
+
+/* ---- micro-benchmark / unit entry points ---- */
+/* data: n = 2^logn elements, 32 B big-endian each, natural order in and out */
+int spp_ntt_fr(spp_ctx* ctx, uint8_t* data, uint32_t logn, int inverse);
+/* sum_i scalars[i] * bases[i]; bases 64 B, scalars 32 B (big-endian); out 64 B. Table-based path. */
+int spp_msm_g1(spp_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, int window_bits, uint8_t out[64]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,82 @@
+// Launch wrappers of the HIP kernels (one .hip file per kernel family), shared by spp_api.cpp.
+// Data layout in HBM, used by every kernel of the proving path ("batch-minor"):
+//   witness   W   [rows][P]      Fr Montgomery, 32 B; row = wire (plus 3 blinding rows r, s, rs)
+//   abc           [3][n][P]      constraint evaluations <A_k,w>, <B_k,w>, <C_k,w>, zero padded to n
+//   MSM tables    [N][Wn][E]     affine multiples (d+1) * 2^(c*j) * Base_i,  E = 2^(c-1)
+//   partials      [S][P]         XYZZ partial sums of one MSM, reduced over S by msm_reduce
+// P (proofs in the batch) is the fastest index everywhere, so a wavefront whose 64 lanes hold 64 proofs
+// reads/writes 2 KiB contiguous per field element and executes one uniform instruction stream.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "bn254.hpp"
+
+namespace spp {
+
+struct DevSparse {
+  const uint32_t* rowptr;
+  const uint32_t* wire;
+  const uint32_t* coeff;   // bit31: coefficient is +1, bit30: coefficient is -1, low bits: table index
+};
+static constexpr uint32_t COEFF_ONE = 0x80000000u;
+static constexpr uint32_t COEFF_MINUS_ONE = 0x40000000u;
+static constexpr uint32_t COEFF_MASK = 0x3fffffffu;
+
+struct DevCircuit {
+  DevSparse A, B, C, H;
+  const Fr* coeffs;
+  const uint32_t* program;
+  uint32_t n_wires, n_constraints, n_public, n_inputs, challenge_wire;
+  // hash constants (Montgomery)
+  const Fr* pos3_rc;  const Fr* pos3_mds;   // t=3: 195 rc, 9 mds (row-major)
+  const Fr* pos5_rc;  const Fr* pos5_mds;   // t=5: 340 rc, 25 mds
+  const Fr* p2_rc;    const Fr* p2_mu;      // 88 rc, 4 mu
+};
+
+// ---- witness ----
+void launch_load_inputs(hipStream_t st, const uint8_t* d_inputs_be, const uint8_t* d_rs_be, Fr* W, uint32_t n_inputs,
+                        uint32_t n_wires, uint32_t P);
+// runs the solver program from word `pc` until OP_COMMIT / OP_END; scratch: [max_batch_div][P] Fr
+void launch_solve(hipStream_t st, DevCircuit dc, Fr* W, Fr* scratch, uint32_t pc, uint32_t P);
+// a,b,c evaluation + satisfaction check (status[p] |= 1 when some row fails)
+void launch_spmv_check(hipStream_t st, DevCircuit dc, const Fr* W, Fr* abc, uint32_t n, uint32_t P, uint32_t* status);
+
+// ---- NTT / QAP ----
+// in-place radix-2 passes over data [n][P]; dif: natural->bitreversed with table tw (w^-k or w^k), else DIT
+void launch_ntt(hipStream_t st, Fr* data, uint32_t logn, uint32_t P, const Fr* tw, bool dif, uint32_t nbatch, size_t batch_stride);
+void launch_scale_rows(hipStream_t st, Fr* data, const Fr* table, uint32_t n, uint32_t P, uint32_t nbatch, size_t batch_stride);
+void launch_qap_pointwise(hipStream_t st, Fr* abc, uint32_t n, uint32_t P, Fr zinv);
+
+// ---- MSM with precomputed window tables ----
+template <class F>
+void launch_build_table(hipStream_t st, const Affine<F>* bases, uint32_t N, uint32_t c, Affine<F>* table, XYZZ<F>* tmp, F* tmp_pre);
+// lane g -> (slice g / P, proof g % P); partial[S][P]
+template <class F>
+void launch_msm_accumulate(hipStream_t st, const Affine<F>* table, const uint32_t* rows, const Fr* scalars, XYZZ<F>* partial, uint32_t N,
+                           uint32_t P, uint32_t c, uint32_t S);
+// out[p] = sum_s partial[s][p]   (S = 0: out[p] = infinity)
+template <class F>
+void launch_msm_reduce(hipStream_t st, const XYZZ<F>* partial, XYZZ<F>* out, uint32_t P, uint32_t S);
+uint32_t msm_windows(uint32_t c);
+uint32_t msm_slices(uint32_t N, uint32_t P);
+
+// ---- commitment challenge, proof assembly ----
+void launch_challenge(hipStream_t st, const G1XYZZ* commit, Fr* W, uint32_t challenge_wire, uint32_t P, G1Affine* commit_affine,
+                      uint32_t* status);
+struct AssembleArgs {
+  const G1XYZZ* mA; const G1XYZZ* mB1; const G2XYZZ* mB2; const G1XYZZ* mK; const G1XYZZ* mZ; const G1XYZZ* mPok;
+  const G1Affine* commit_affine;
+  const Fr* W; uint32_t row_r, row_s; uint32_t n_public;
+  uint8_t* proofs;   // [P][388]
+  uint8_t* pws;      // [P][12+32*(n_public-1)]
+  uint32_t P;
+};
+void launch_assemble(hipStream_t st, AssembleArgs a);
+
+// ---- setup helpers ----
+// out[i] = scalars[i] * G for a generator table built with launch_build_table (N=1)
+template <class F>
+void launch_fixed_base_mul(hipStream_t st, const Affine<F>* gen_table, uint32_t c, const Fr* scalars, uint32_t n, Affine<F>* out,
+                           XYZZ<F>* tmp);
+
+}  // namespace spp

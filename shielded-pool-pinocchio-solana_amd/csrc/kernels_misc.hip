@@ -1,0 +1,149 @@
+// BSB22 commitment challenge (SHA-256 hash-to-field on the GPU) and proof assembly / serialisation.
+//
+// Replaces the tail of gnark's Prove inside `sunspot prove` (client/proof.helper.ts:64): the commitment
+// hint (challenge = fr.Hash(commitment, "bsb22-commitment")), the blinding Ar/Bs/Krs combination and
+// Proof.WriteRawTo + the public-witness writer.  Output bytes follow shielded_pool_program/src/
+// instructions/withdraw.rs:13-16 (388-byte proof, 12-byte header + 32 B per public input).
+#include "kernels.hpp"
+#include "sha256.hpp"
+
+namespace spp {
+
+__device__ __forceinline__ void fq_to_be_words(const Fq& a, uint32_t* w) {
+  uint32_t c[8];
+  a.to_canonical(c);
+  SPP_UNROLL for (int i = 0; i < 8; i++) w[i] = c[7 - i];
+}
+__device__ __forceinline__ void fr_to_be_words(const Fr& a, uint32_t* w) {
+  uint32_t c[8];
+  a.to_canonical(c);
+  SPP_UNROLL for (int i = 0; i < 8; i++) w[i] = c[7 - i];
+}
+__device__ __forceinline__ void store_be_words(uint8_t* dst, const uint32_t* w, int nwords) {
+  for (int i = 0; i < nwords; i++) {
+    dst[4 * i] = (uint8_t)(w[i] >> 24);
+    dst[4 * i + 1] = (uint8_t)(w[i] >> 16);
+    dst[4 * i + 2] = (uint8_t)(w[i] >> 8);
+    dst[4 * i + 3] = (uint8_t)w[i];
+  }
+}
+
+// one lane per proof: commitment -> affine -> expand_message_xmd(SHA-256) -> challenge wire
+__global__ void __launch_bounds__(64) k_challenge(const G1XYZZ* __restrict__ commit, Fr* __restrict__ W, uint32_t challenge_wire, uint32_t P,
+                                                  G1Affine* __restrict__ commit_affine) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  G1Affine c = commit[p].to_affine();
+  commit_affine[p] = c;
+  uint32_t m[16];
+  fq_to_be_words(c.x, m);
+  fq_to_be_words(c.y, m + 8);   // infinity -> x = y = 0 -> 64 zero bytes, as gnark's Marshal
+  uint32_t blk[16];
+  // b0 = H(Z_pad || msg || I2OSP(48,2) || 0 || DST || len(DST))
+  Sha256 s0;
+  s0.init();
+  for (int i = 0; i < 16; i++) blk[i] = 0;
+  s0.compress(blk);
+  s0.compress(m);
+  blk[0] = 0x00300062u; blk[1] = 0x73623232u; blk[2] = 0x2d636f6du; blk[3] = 0x6d69746du; blk[4] = 0x656e7410u; blk[5] = 0x80000000u;
+  for (int i = 6; i < 15; i++) blk[i] = 0;
+  blk[15] = 0x4a0u;
+  s0.compress(blk);
+  // b1 = H(b0 || 1 || DST')
+  Sha256 s1;
+  s1.init();
+  for (int i = 0; i < 8; i++) blk[i] = s0.h[i];
+  blk[8] = 0x01627362u; blk[9] = 0x32322d63u; blk[10] = 0x6f6d6d69u; blk[11] = 0x746d656eu; blk[12] = 0x74108000u;
+  blk[13] = 0; blk[14] = 0; blk[15] = 0x190u;
+  s1.compress(blk);
+  // b2 = H((b0 ^ b1) || 2 || DST')
+  Sha256 s2;
+  s2.init();
+  for (int i = 0; i < 8; i++) blk[i] = s0.h[i] ^ s1.h[i];
+  blk[8] = 0x02627362u;
+  s2.compress(blk);
+  uint32_t wide[12];
+  for (int i = 0; i < 8; i++) wide[i] = s1.h[i];
+  for (int i = 0; i < 4; i++) wide[8 + i] = s2.h[i];
+  W[(size_t)challenge_wire * P + p] = fr_from_wide48(wide);
+}
+void launch_challenge(hipStream_t st, const G1XYZZ* commit, Fr* W, uint32_t challenge_wire, uint32_t P, G1Affine* commit_affine,
+                      uint32_t* /*status*/) {
+  hipLaunchKernelGGL(k_challenge, dim3((P + 63) / 64), dim3(64), 0, st, commit, W, challenge_wire, P, commit_affine);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// assembly: lane 2p computes s*Ar, lane 2p+1 computes r*Bs1 (the only variable-base work of a proof);
+// the pair is combined through LDS and lane 2p serialises.
+// ---------------------------------------------------------------------------------------------------
+__device__ __noinline__ G1XYZZ dev_scalar_mul_g1(const G1Affine& base, const uint32_t k[8]) {
+  G1XYZZ acc = G1XYZZ::infinity();
+#pragma unroll 1
+  for (int w = 7; w >= 0; w--) {
+    const uint32_t kw = w == 7 ? k[7] : w == 6 ? k[6] : w == 5 ? k[5] : w == 4 ? k[4] : w == 3 ? k[3] : w == 2 ? k[2] : w == 1 ? k[1] : k[0];
+#pragma unroll 1
+    for (int b = 31; b >= 0; b--) {
+      acc.dbl_inplace();
+      if ((kw >> b) & 1) acc.madd(base);
+    }
+  }
+  return acc;
+}
+
+__global__ void __launch_bounds__(64) k_assemble(AssembleArgs a) {
+  __shared__ G1XYZZ sh[64];
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t p = g >> 1, role = g & 1;
+  const bool live = p < a.P;
+  G1Affine base = G1Affine::infinity();
+  uint32_t k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (live) {
+    base = (role == 0 ? a.mA[p] : a.mB1[p]).to_affine();
+    // role 0: s * Ar ; role 1: r * Bs1
+    const Fr sc = a.W[(size_t)(role == 0 ? a.row_s : a.row_r) * a.P + p];
+    sc.to_canonical(k);
+  }
+  G1XYZZ part = dev_scalar_mul_g1(base, k);
+  sh[threadIdx.x] = part;
+  __syncthreads();
+  if (!live || role != 0) return;
+  G1XYZZ krs = a.mK[p];
+  krs.add(a.mZ[p]);
+  krs.add(part);
+  krs.add(sh[threadIdx.x + 1]);
+  G1Affine Ar = base;
+  G1Affine Krs = krs.to_affine();
+  G2Affine Bs = a.mB2[p].to_affine();
+  G1Affine Pok = a.mPok[p].to_affine();
+  G1Affine Cm = a.commit_affine[p];
+  uint8_t* out = a.proofs + (size_t)p * 388;
+  uint32_t w[8];
+  fq_to_be_words(Ar.x, w); store_be_words(out, w, 8);
+  fq_to_be_words(Ar.y, w); store_be_words(out + 32, w, 8);
+  fq_to_be_words(Bs.x.c1, w); store_be_words(out + 64, w, 8);
+  fq_to_be_words(Bs.x.c0, w); store_be_words(out + 96, w, 8);
+  fq_to_be_words(Bs.y.c1, w); store_be_words(out + 128, w, 8);
+  fq_to_be_words(Bs.y.c0, w); store_be_words(out + 160, w, 8);
+  fq_to_be_words(Krs.x, w); store_be_words(out + 192, w, 8);
+  fq_to_be_words(Krs.y, w); store_be_words(out + 224, w, 8);
+  out[256] = 0; out[257] = 0; out[258] = 0; out[259] = 1;
+  fq_to_be_words(Cm.x, w); store_be_words(out + 260, w, 8);
+  fq_to_be_words(Cm.y, w); store_be_words(out + 292, w, 8);
+  fq_to_be_words(Pok.x, w); store_be_words(out + 324, w, 8);
+  fq_to_be_words(Pok.y, w); store_be_words(out + 356, w, 8);
+  // public witness: u32be nPublic, u32be 0, u32be nPublic, then values
+  const uint32_t np = a.n_public - 1;
+  uint8_t* pw = a.pws + (size_t)p * (12 + 32 * np);
+  uint32_t hdr[3] = {np, 0, np};
+  store_be_words(pw, hdr, 3);
+  for (uint32_t i = 0; i < np; i++) {
+    fr_to_be_words(a.W[(size_t)(1 + i) * a.P + p], w);
+    store_be_words(pw + 12 + 32 * i, w, 8);
+  }
+}
+void launch_assemble(hipStream_t st, AssembleArgs a) {
+  uint32_t lanes = 2 * a.P;
+  hipLaunchKernelGGL(k_assemble, dim3((lanes + 63) / 64), dim3(64), 0, st, a);
+}
+
+}  // namespace spp

@@ -1,0 +1,236 @@
+// Fixed-base multi-scalar multiplication for batched Groth16 proving on gfx950.
+//
+// Replaces the Pippenger MSMs of gnark's Prove: Ar / Bs1 / Krs over pk.G1.{A,B,K,Z},
+// Bs over pk.G2.B, and the BSB22 Pedersen commitment + proof of knowledge. In the reference these run
+// inside `sunspot prove` (client/proof.helper.ts:64) on CPU threads, one proof at a time.
+//
+// MI355X design: the proving key is constant across a batch and there are 288 GB of HBM, so every base
+// carries a precomputed table of its window multiples  T[i][j][d] = (d+1) * 2^(c*j) * Base_i  (affine,
+// d < 2^(c-1), signed digits).  An MSM then needs no buckets, no sorting and no bucket reduction: each
+// lane owns one proof of the batch and folds  sum_i sum_j  +-T[i][j][|digit|]  into a private XYZZ
+// accumulator with mixed additions (8M+2S).  All 64 lanes of a wave walk the SAME (i, j) sequence, so
+// scalar loads are one coalesced 2 KiB row, table gathers hit one 2^(c-1)*64 B segment, control flow is
+// uniform, and windows in which every proof has a zero digit (bits, bytes, small signed noise -- most of
+// the audit witness) are skipped for the whole wave.  Work is split over S slices of the base range to
+// fill 256 CUs; a second kernel folds the S partial sums per proof through LDS.
+#include "kernels.hpp"
+
+namespace spp {
+
+uint32_t msm_windows(uint32_t c) { return (254 + c - 1) / c; }
+
+// enough (slice, proof) lanes to fill 256 CUs x 4 SIMDs x ~4 waves, but at least 4 bases per slice
+uint32_t msm_slices(uint32_t N, uint32_t P) {
+  const uint32_t target_lanes = 256u * 4u * 4u * 64u;
+  uint32_t S = (target_lanes + P - 1) / P;
+  uint32_t maxS = (N + 3) / 4;
+  if (maxS == 0) maxS = 1;
+  if (S > maxS) S = maxS;
+  if (S == 0) S = 1;
+  return S;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// table construction: one lane per (base, window) row
+// ----------------------------------------------------------------------------------------------------
+template <class F>
+__global__ void __launch_bounds__(64) k_build_table(const Affine<F>* __restrict__ bases, uint32_t N, uint32_t c, uint32_t Wn,
+                                                    Affine<F>* __restrict__ table, XYZZ<F>* __restrict__ tmp,
+                                                    F* __restrict__ tmp_pre) {
+  const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= N * Wn) return;
+  const uint32_t i = row / Wn, j = row % Wn;
+  const uint32_t E = 1u << (c - 1);
+  Affine<F>* out = table + (size_t)row * E;
+  XYZZ<F>* t = tmp + (size_t)row * E;
+  F* pre = tmp_pre + (size_t)row * E;
+  Affine<F> base = bases[i];
+  if (base.is_inf()) {
+    for (uint32_t d = 0; d < E; d++) out[d] = Affine<F>::infinity();
+    return;
+  }
+  XYZZ<F> b = XYZZ<F>::from_affine(base);
+  for (uint32_t k = 0; k < c * j; k++) b.dbl_inplace();
+  Affine<F> bj = b.to_affine();
+  XYZZ<F> acc = XYZZ<F>::from_affine(bj);
+  F prod = F::one();
+  for (uint32_t d = 0; d < E; d++) {
+    t[d] = acc;
+    pre[d] = prod;
+    prod = prod * (acc.ZZ * acc.ZZZ);
+    acc.madd(bj);
+  }
+  F inv = prod.inv();
+  for (uint32_t d = E; d-- > 0;) {
+    XYZZ<F> q = t[d];
+    F I = inv * pre[d];
+    inv = inv * (q.ZZ * q.ZZZ);
+    F izz = I * q.ZZZ;
+    F izzz = I * q.ZZ;
+    out[d] = {q.X * izz, q.Y * izzz};
+  }
+}
+
+template <class F>
+void launch_build_table(hipStream_t st, const Affine<F>* bases, uint32_t N, uint32_t c, Affine<F>* table, XYZZ<F>* tmp, F* tmp_pre) {
+  uint32_t rows = N * msm_windows(c);
+  if (rows == 0) return;
+  hipLaunchKernelGGL(k_build_table<F>, dim3((rows + 63) / 64), dim3(64), 0, st, bases, N, c, msm_windows(c), table, tmp, tmp_pre);
+}
+template void launch_build_table<Fq>(hipStream_t, const Affine<Fq>*, uint32_t, uint32_t, Affine<Fq>*, XYZZ<Fq>*, Fq*);
+template void launch_build_table<Fq2>(hipStream_t, const Affine<Fq2>*, uint32_t, uint32_t, Affine<Fq2>*, XYZZ<Fq2>*, Fq2*);
+
+// ----------------------------------------------------------------------------------------------------
+// signed-window recoding helpers (scalar in canonical limbs, magnitude < 2^253 after sign folding)
+// ----------------------------------------------------------------------------------------------------
+struct Recoder {
+  uint32_t l[8];
+  uint32_t carry;
+  bool neg;
+  __device__ __forceinline__ void init(const Fr& s) {
+    uint32_t cl[8];
+    s.to_canonical(cl);
+    neg = canonical_gt_half<FrParams>(cl);
+    if (neg) {
+      canonical_negate<FrParams>(cl, l);
+    } else {
+      SPP_UNROLL for (int k = 0; k < 8; k++) l[k] = cl[k];
+    }
+    carry = 0;
+  }
+  __device__ __forceinline__ bool rest_is_zero() const {
+    uint32_t o = carry;
+    SPP_UNROLL for (int k = 0; k < 8; k++) o |= l[k];
+    return o == 0;
+  }
+  // next window: returns magnitude (0..2^(c-1)) and sign (true = subtract)
+  __device__ __forceinline__ uint32_t next(uint32_t c, bool& sgn) {
+    const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
+    uint32_t d = (l[0] & mask) + carry;
+    SPP_UNROLL for (int k = 0; k < 7; k++) l[k] = (l[k] >> c) | (l[k + 1] << (32 - c));
+    l[7] >>= c;
+    if (d > half) {
+      d = (1u << c) - d;
+      carry = 1;
+      sgn = !neg;
+    } else {
+      carry = 0;
+      sgn = neg;
+    }
+    return d;
+  }
+};
+
+// ----------------------------------------------------------------------------------------------------
+// MSM accumulate: lane g -> (slice = g / P, proof p = g % P)
+// ----------------------------------------------------------------------------------------------------
+template <class F>
+__global__ void __launch_bounds__(256) k_msm_fixed(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ rows,
+                                                   const Fr* __restrict__ scalars, XYZZ<F>* __restrict__ partial, uint32_t N,
+                                                   uint32_t P, uint32_t c, uint32_t Wn, uint32_t S, uint32_t L) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= S * P) return;
+  const uint32_t p = g % P, slice = g / P;
+  const uint32_t E = 1u << (c - 1);
+  uint32_t i0 = slice * L, i1 = i0 + L;
+  if (i1 > N) i1 = N;
+  XYZZ<F> acc = XYZZ<F>::infinity();
+  for (uint32_t i = i0; i < i1; i++) {
+    Fr s = scalars[(size_t)rows[i] * P + p];
+    if (s.is_zero()) continue;
+    Recoder rc;
+    rc.init(s);
+    const Affine<F>* trow = table + (size_t)i * Wn * E;
+#pragma unroll 1
+    for (uint32_t j = 0; j < Wn; j++) {
+      if (rc.rest_is_zero()) break;
+      bool sgn;
+      uint32_t d = rc.next(c, sgn);
+      if (d != 0) {
+        Affine<F> e = trow[(size_t)j * E + (d - 1)];
+        if (sgn) e.y = e.y.neg();
+        acc.madd(e);
+      }
+    }
+  }
+  partial[(size_t)slice * P + p] = acc;
+}
+
+// fold S partial sums per proof: one 64-lane block per proof
+template <class F>
+__global__ void __launch_bounds__(64) k_msm_reduce(const XYZZ<F>* __restrict__ partial, XYZZ<F>* __restrict__ out, uint32_t P,
+                                                   uint32_t S) {
+  __shared__ XYZZ<F> sh[64];
+  const uint32_t p = blockIdx.x, t = threadIdx.x;
+  XYZZ<F> acc = XYZZ<F>::infinity();
+  for (uint32_t s = t; s < S; s += 64) acc.add(partial[(size_t)s * P + p]);
+  sh[t] = acc;
+  __syncthreads();
+  for (uint32_t w = 32; w > 0; w >>= 1) {
+    if (t < w) {
+      XYZZ<F> a = sh[t];
+      a.add(sh[t + w]);
+      sh[t] = a;
+    }
+    __syncthreads();
+  }
+  if (t == 0) out[p] = sh[0];
+}
+
+template <class F>
+void launch_msm_accumulate(hipStream_t st, const Affine<F>* table, const uint32_t* rows, const Fr* scalars, XYZZ<F>* partial, uint32_t N,
+                           uint32_t P, uint32_t c, uint32_t S) {
+  if (N == 0 || S == 0) return;
+  uint32_t L = (N + S - 1) / S;
+  uint64_t lanes = (uint64_t)S * P;
+  hipLaunchKernelGGL(k_msm_fixed<F>, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, st, table, rows, scalars, partial, N, P, c,
+                     msm_windows(c), S, L);
+}
+template <class F>
+void launch_msm_reduce(hipStream_t st, const XYZZ<F>* partial, XYZZ<F>* out, uint32_t P, uint32_t S) {
+  hipLaunchKernelGGL(k_msm_reduce<F>, dim3(P), dim3(64), 0, st, partial, out, P, S);
+}
+template void launch_msm_accumulate<Fq>(hipStream_t, const Affine<Fq>*, const uint32_t*, const Fr*, XYZZ<Fq>*, uint32_t, uint32_t, uint32_t,
+                                        uint32_t);
+template void launch_msm_accumulate<Fq2>(hipStream_t, const Affine<Fq2>*, const uint32_t*, const Fr*, XYZZ<Fq2>*, uint32_t, uint32_t,
+                                         uint32_t, uint32_t);
+template void launch_msm_reduce<Fq>(hipStream_t, const XYZZ<Fq>*, XYZZ<Fq>*, uint32_t, uint32_t);
+template void launch_msm_reduce<Fq2>(hipStream_t, const XYZZ<Fq2>*, XYZZ<Fq2>*, uint32_t, uint32_t);
+
+// ----------------------------------------------------------------------------------------------------
+// setup: out[i] = scalars[i] * G using the window table of the single base G
+// ----------------------------------------------------------------------------------------------------
+template <class F>
+__global__ void __launch_bounds__(64) k_fixed_base_mul(const Affine<F>* __restrict__ gen_table, uint32_t c, uint32_t Wn,
+                                                       const Fr* __restrict__ scalars, uint32_t n, Affine<F>* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t E = 1u << (c - 1);
+  Fr s = scalars[i];
+  XYZZ<F> acc = XYZZ<F>::infinity();
+  if (!s.is_zero()) {
+    Recoder rc;
+    rc.init(s);
+#pragma unroll 1
+    for (uint32_t j = 0; j < Wn; j++) {
+      bool sgn;
+      uint32_t d = rc.next(c, sgn);
+      if (d != 0) {
+        Affine<F> e = gen_table[(size_t)j * E + (d - 1)];
+        if (sgn) e.y = e.y.neg();
+        acc.madd(e);
+      }
+    }
+  }
+  out[i] = acc.to_affine();
+}
+template <class F>
+void launch_fixed_base_mul(hipStream_t st, const Affine<F>* gen_table, uint32_t c, const Fr* scalars, uint32_t n, Affine<F>* out,
+                           XYZZ<F>* /*tmp*/) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_fixed_base_mul<F>, dim3((n + 63) / 64), dim3(64), 0, st, gen_table, c, msm_windows(c), scalars, n, out);
+}
+template void launch_fixed_base_mul<Fq>(hipStream_t, const Affine<Fq>*, uint32_t, const Fr*, uint32_t, Affine<Fq>*, XYZZ<Fq>*);
+template void launch_fixed_base_mul<Fq2>(hipStream_t, const Affine<Fq2>*, uint32_t, const Fr*, uint32_t, Affine<Fq2>*, XYZZ<Fq2>*);
+
+}  // namespace spp

@@ -1,0 +1,297 @@
+// Witness generation on the GPU: input decoding, the solver-program interpreter (one lane per proof),
+// and the constraint-matrix evaluation <A,w>, <B,w>, <C,w> with the satisfaction check.
+//
+// Replaces the two CPU stages the reference spawns per proof: `nargo execute` (ACVM witness solving,
+// client/proof.helper.ts:55) and gnark's R1CS solver inside `sunspot prove` (client/proof.helper.ts:64),
+// for the circuits of noir_circuit/src/main.nr:38-82 and scripts/generate_audit.py:405-463.
+// Every lane of a wave executes the same instruction stream on its own proof (column p of W[.][P]), so
+// there is no divergence and every witness access is a coalesced 2 KiB row segment.  Poseidon / Poseidon2
+// permutations (main.nr:1-9, ct_helper/src/main.nr:15-34) run natively with the state in registers and
+// emit the x^2, x^4, x^5 wires of every S-box as they go.
+#include "kernels.hpp"
+#include "circuit.hpp"   // opcodes only
+
+namespace spp {
+
+__device__ __forceinline__ Fr dev_row_dot(const DevSparse& m, const Fr* __restrict__ coeffs, uint32_t k, uint32_t k_end_skip,
+                                           const Fr* __restrict__ W, uint32_t P, uint32_t p) {
+  Fr acc = Fr::zero();
+  const uint32_t b = m.rowptr[k], e = m.rowptr[k + 1] - k_end_skip;
+  for (uint32_t t = b; t < e; t++) {
+    const uint32_t ci = m.coeff[t];
+    Fr w = W[(size_t)m.wire[t] * P + p];
+    if (ci & COEFF_ONE) acc = acc + w;
+    else if (ci & COEFF_MINUS_ONE) acc = acc - w;
+    else acc = acc + coeffs[ci & COEFF_MASK] * w;
+  }
+  return acc;
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_load_inputs(const uint8_t* __restrict__ in_be, const uint8_t* __restrict__ rs_be,
+                                                     Fr* __restrict__ W, uint32_t n_inputs, uint32_t n_wires, uint32_t P) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t total = (uint64_t)(n_inputs + 2) * P;
+  if (g >= total) return;
+  const uint32_t p = (uint32_t)(g % P), idx = (uint32_t)(g / P);
+  uint8_t buf[32];
+  if (idx < n_inputs) {
+    const uint8_t* src = in_be + ((size_t)p * n_inputs + idx) * 32;
+    for (int i = 0; i < 32; i++) buf[i] = src[i];
+    W[(size_t)(1 + idx) * P + p] = Fr::from_bytes_be(buf);
+    if (idx == 0) W[p] = Fr::one();
+  } else if (idx == n_inputs) {
+    // blinding r, s and their product: rows n_wires, n_wires+1, n_wires+2
+    const uint8_t* src = rs_be + (size_t)p * 64;
+    for (int i = 0; i < 32; i++) buf[i] = src[i];
+    Fr r = Fr::from_bytes_be(buf);
+    for (int i = 0; i < 32; i++) buf[i] = src[32 + i];
+    Fr s = Fr::from_bytes_be(buf);
+    W[(size_t)n_wires * P + p] = r;
+    W[(size_t)(n_wires + 1) * P + p] = s;
+    W[(size_t)(n_wires + 2) * P + p] = r * s;
+  }
+}
+void launch_load_inputs(hipStream_t st, const uint8_t* d_inputs_be, const uint8_t* d_rs_be, Fr* W, uint32_t n_inputs, uint32_t n_wires,
+                        uint32_t P) {
+  uint64_t total = (uint64_t)(n_inputs + 2) * P;
+  hipLaunchKernelGGL(k_load_inputs, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, d_inputs_be, d_rs_be, W, n_inputs, n_wires, P);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// native permutations
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ Fr dev_sbox_emit(const Fr& x, Fr* __restrict__ W, uint32_t& out, uint32_t P, uint32_t p) {
+  Fr x2 = x.sqr();
+  Fr x4 = x2.sqr();
+  Fr x5 = x4 * x;
+  W[(size_t)out * P + p] = x2;
+  W[(size_t)(out + 1) * P + p] = x4;
+  W[(size_t)(out + 2) * P + p] = x5;
+  out += 3;
+  return x5;
+}
+
+template <int T>
+__device__ __noinline__ void dev_poseidon(Fr (&s)[T], const Fr* __restrict__ rc, const Fr* __restrict__ mds, int rp, Fr* __restrict__ W,
+                                          uint32_t out, uint32_t P, uint32_t p) {
+  const int rf = 8;
+#pragma unroll 1
+  for (int r = 0; r < rf + rp; r++) {
+    SPP_UNROLL for (int i = 0; i < T; i++) s[i] = s[i] + rc[r * T + i];
+    const bool full = r < rf / 2 || r >= rf / 2 + rp;
+    if (full) {
+      SPP_UNROLL for (int i = 0; i < T; i++) s[i] = dev_sbox_emit(s[i], W, out, P, p);
+    } else {
+      s[0] = dev_sbox_emit(s[0], W, out, P, p);
+    }
+    Fr nx[T];
+    SPP_UNROLL for (int i = 0; i < T; i++) {
+      nx[i] = mds[i * T] * s[0];
+      SPP_UNROLL for (int j = 1; j < T; j++) nx[i] = nx[i] + mds[i * T + j] * s[j];
+    }
+    SPP_UNROLL for (int i = 0; i < T; i++) s[i] = nx[i];
+  }
+}
+
+__device__ __forceinline__ void dev_p2_external(Fr (&s)[4]) {
+  // rows (5,7,1,3),(4,6,1,1),(1,3,5,7),(1,1,4,6)
+  Fr t01 = s[0] + s[1], t23 = s[2] + s[3];
+  Fr d0 = s[0].dbl(), d1 = s[1].dbl(), d2 = s[2].dbl(), d3 = s[3].dbl();
+  Fr q0 = d0.dbl(), q1 = d1.dbl(), q2 = d2.dbl(), q3 = d3.dbl();
+  Fr n0 = q0 + s[0] + q1 + d1 + s[1] + s[2] + d3 + s[3];          // 5a+7b+c+3d
+  Fr n1 = q0 + q1 + d1 + t23;                                      // 4a+6b+c+d
+  Fr n2 = s[0] + d1 + s[1] + q2 + s[2] + q3 + d3 + s[3];          // a+3b+5c+7d
+  Fr n3 = t01 + q2 + q3 + d3;                                      // a+b+4c+6d
+  s[0] = n0; s[1] = n1; s[2] = n2; s[3] = n3;
+}
+
+__device__ __noinline__ void dev_poseidon2(Fr (&s)[4], const Fr* __restrict__ rc, const Fr* __restrict__ mu, Fr* __restrict__ W,
+                                           uint32_t out, uint32_t P, uint32_t p) {
+  dev_p2_external(s);
+  int k = 0;
+#pragma unroll 1
+  for (int r = 0; r < 4; r++) {
+    SPP_UNROLL for (int i = 0; i < 4; i++) s[i] = dev_sbox_emit(s[i] + rc[k + i], W, out, P, p);
+    k += 4;
+    dev_p2_external(s);
+  }
+#pragma unroll 1
+  for (int r = 0; r < 56; r++) {
+    s[0] = dev_sbox_emit(s[0] + rc[k], W, out, P, p);
+    k++;
+    Fr tot = s[0] + s[1] + s[2] + s[3];
+    SPP_UNROLL for (int i = 0; i < 4; i++) s[i] = mu[i] * s[i] + tot;
+  }
+#pragma unroll 1
+  for (int r = 0; r < 4; r++) {
+    SPP_UNROLL for (int i = 0; i < 4; i++) s[i] = dev_sbox_emit(s[i] + rc[k + i], W, out, P, p);
+    k += 4;
+    dev_p2_external(s);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// solver interpreter
+// ---------------------------------------------------------------------------------------------------
+__device__ __noinline__ void dev_div_range(const DevCircuit& dc, Fr* __restrict__ W, Fr* __restrict__ scratch, uint32_t k0, uint32_t n,
+                                           uint32_t P, uint32_t p) {
+  Fr prod = Fr::one();
+  for (uint32_t i = 0; i < n; i++) {
+    Fr den = dev_row_dot(dc.B, dc.coeffs, k0 + i, 0, W, P, p);
+    scratch[(size_t)i * P + p] = prod;
+    if (!den.is_zero()) prod = prod * den;
+  }
+  Fr inv = prod.inv();
+  for (uint32_t i = n; i-- > 0;) {
+    const uint32_t k = k0 + i;
+    const uint32_t out = dc.A.wire[dc.A.rowptr[k]];
+    Fr den = dev_row_dot(dc.B, dc.coeffs, k, 0, W, P, p);
+    if (den.is_zero()) {
+      W[(size_t)out * P + p] = Fr::zero();
+      continue;
+    }
+    Fr di = inv * scratch[(size_t)i * P + p];
+    inv = inv * den;
+    Fr num = dev_row_dot(dc.C, dc.coeffs, k, 0, W, P, p);
+    W[(size_t)out * P + p] = num * di;
+  }
+}
+
+__global__ void __launch_bounds__(64) k_solve(DevCircuit dc, Fr* __restrict__ W, Fr* __restrict__ scratch, uint32_t pc, uint32_t P) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const uint32_t* __restrict__ pr = dc.program;
+  for (;;) {
+    const uint32_t op = pr[pc];
+    if (op == OP_END || op == OP_COMMIT) break;
+    switch (op) {
+      case OP_SOLVE_C: {
+        const uint32_t k = pr[pc + 1];
+        pc += 2;
+        Fr a = dev_row_dot(dc.A, dc.coeffs, k, 0, W, P, p);
+        Fr b = dev_row_dot(dc.B, dc.coeffs, k, 0, W, P, p);
+        Fr rest = dev_row_dot(dc.C, dc.coeffs, k, 1, W, P, p);
+        const uint32_t out = dc.C.wire[dc.C.rowptr[k + 1] - 1];
+        W[(size_t)out * P + p] = a * b - rest;
+        break;
+      }
+      case OP_SOLVE_A: {
+        dev_div_range(dc, W, scratch, pr[pc + 1], 1, P, p);
+        pc += 2;
+        break;
+      }
+      case OP_BATCH_DIV: {
+        dev_div_range(dc, W, scratch, pr[pc + 1], pr[pc + 2], P, p);
+        pc += 3;
+        break;
+      }
+      case OP_BITS: {
+        const uint32_t h = pr[pc + 1], nb = pr[pc + 2], out0 = pr[pc + 3];
+        pc += 4;
+        Fr v = dev_row_dot(dc.H, dc.coeffs, h, 0, W, P, p);
+        uint32_t c[8];
+        v.to_canonical(c);
+        const Fr one = Fr::one(), zero = Fr::zero();
+        uint32_t word = 0;
+        for (uint32_t i = 0; i < nb; i++) {
+          if ((i & 31) == 0) {
+            // select limb i/32 without dynamic register indexing
+            const uint32_t li = i >> 5;
+            word = li == 0 ? c[0] : li == 1 ? c[1] : li == 2 ? c[2] : li == 3 ? c[3] : li == 4 ? c[4] : li == 5 ? c[5] : li == 6 ? c[6] : c[7];
+          }
+          W[(size_t)(out0 + i) * P + p] = (word & 1) ? one : zero;
+          word >>= 1;
+        }
+        break;
+      }
+      case OP_LIMBS8: {
+        const uint32_t h = pr[pc + 1], nl = pr[pc + 2], out0 = pr[pc + 3];
+        pc += 4;
+        Fr v = dev_row_dot(dc.H, dc.coeffs, h, 0, W, P, p);
+        uint32_t c[8];
+        v.to_canonical(c);
+        uint32_t word = 0;
+        for (uint32_t i = 0; i < nl; i++) {
+          if ((i & 3) == 0) {
+            const uint32_t li = i >> 2;
+            word = li == 0 ? c[0] : li == 1 ? c[1] : li == 2 ? c[2] : li == 3 ? c[3] : li == 4 ? c[4] : li == 5 ? c[5] : li == 6 ? c[6] : c[7];
+          }
+          W[(size_t)(out0 + i) * P + p] = Fr::from_u64(word & 0xFF);
+          word >>= 8;
+        }
+        break;
+      }
+      case OP_COUNT8: {
+        const uint32_t h0 = pr[pc + 1], n = pr[pc + 2], out0 = pr[pc + 3];
+        pc += 4;
+        const Fr one = Fr::one();
+        for (uint32_t j = 0; j < 256; j++) W[(size_t)(out0 + j) * P + p] = Fr::zero();
+        for (uint32_t i = 0; i < n; i++) {
+          Fr v = dev_row_dot(dc.H, dc.coeffs, h0 + i, 0, W, P, p);
+          uint32_t c[8];
+          v.to_canonical(c);
+          if (c[0] < 256 && (c[1] | c[2] | c[3] | c[4] | c[5] | c[6] | c[7]) == 0) {
+            Fr* slot = &W[(size_t)(out0 + c[0]) * P + p];
+            *slot = *slot + one;
+          }
+        }
+        break;
+      }
+      case OP_POSEIDON: {
+        const uint32_t t = pr[pc + 1], h0 = pr[pc + 2], out0 = pr[pc + 3];
+        pc += 4;
+        if (t == 3) {
+          Fr s[3];
+          SPP_UNROLL for (int i = 0; i < 3; i++) s[i] = dev_row_dot(dc.H, dc.coeffs, h0 + i, 0, W, P, p);
+          dev_poseidon<3>(s, dc.pos3_rc, dc.pos3_mds, 57, W, out0, P, p);
+        } else {
+          Fr s[5];
+          SPP_UNROLL for (int i = 0; i < 5; i++) s[i] = dev_row_dot(dc.H, dc.coeffs, h0 + i, 0, W, P, p);
+          dev_poseidon<5>(s, dc.pos5_rc, dc.pos5_mds, 60, W, out0, P, p);
+        }
+        break;
+      }
+      case OP_POSEIDON2: {
+        const uint32_t h0 = pr[pc + 1], out0 = pr[pc + 2];
+        pc += 3;
+        Fr s[4];
+        SPP_UNROLL for (int i = 0; i < 4; i++) s[i] = dev_row_dot(dc.H, dc.coeffs, h0 + i, 0, W, P, p);
+        dev_poseidon2(s, dc.p2_rc, dc.p2_mu, W, out0, P, p);
+        break;
+      }
+      default:
+        return;  // unknown opcode: leave the remaining wires zero -> unsatisfied
+    }
+  }
+}
+void launch_solve(hipStream_t st, DevCircuit dc, Fr* W, Fr* scratch, uint32_t pc, uint32_t P) {
+  hipLaunchKernelGGL(k_solve, dim3((P + 63) / 64), dim3(64), 0, st, dc, W, scratch, pc, P);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// constraint evaluation + satisfaction check: lane -> (constraint k, proof p)
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_spmv_check(DevCircuit dc, const Fr* __restrict__ W, Fr* __restrict__ abc, uint32_t n, uint32_t P,
+                                                    uint32_t* __restrict__ status) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t total = (uint64_t)n * P;
+  if (g >= total) return;
+  const uint32_t p = (uint32_t)(g % P), k = (uint32_t)(g / P);
+  Fr a = Fr::zero(), b = Fr::zero(), c = Fr::zero();
+  if (k < dc.n_constraints) {
+    a = dev_row_dot(dc.A, dc.coeffs, k, 0, W, P, p);
+    b = dev_row_dot(dc.B, dc.coeffs, k, 0, W, P, p);
+    c = dev_row_dot(dc.C, dc.coeffs, k, 0, W, P, p);
+    if (a * b != c) atomicOr(&status[p], 1u);
+  }
+  abc[g] = a;
+  abc[total + g] = b;
+  abc[2 * total + g] = c;
+}
+void launch_spmv_check(hipStream_t st, DevCircuit dc, const Fr* W, Fr* abc, uint32_t n, uint32_t P, uint32_t* status) {
+  uint64_t total = (uint64_t)n * P;
+  hipLaunchKernelGGL(k_spmv_check, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, dc, W, abc, n, P, status);
+}
+
+}  // namespace spp

@@ -1,0 +1,1029 @@
+// libspp C ABI (include/spp.h): host orchestration of the HIP proving pipeline.
+// Everything heavy runs on the GPU; the host parses containers, derives one-time constants and enqueues
+// kernels on one stream per context.  There is deliberately no CPU implementation of the hot path here.
+#include "../../include/spp.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "circuit.hpp"
+#include "kernels.hpp"
+#include "sha256.hpp"
+
+using namespace spp;
+
+// -----------------------------------------------------------------------------------------------------
+// errors
+// -----------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) return fail(SPP_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e));     \
+  } while (0)
+
+extern "C" const char* spp_last_error(void) { return g_err; }
+extern "C" const char* spp_version(void) { return "libspp 0.1 (gfx950)"; }
+
+// -----------------------------------------------------------------------------------------------------
+// host helpers
+// -----------------------------------------------------------------------------------------------------
+static Fr fr_pow_limbs(const Fr& base, const uint32_t e[8]) {
+  Fr acc = Fr::one(), b = base;
+  for (int w = 0; w < 8; w++)
+    for (int i = 0; i < 32; i++) {
+      if ((e[w] >> i) & 1) acc = acc * b;
+      b = b.sqr();
+    }
+  return acc;
+}
+static Fr fr_root_of_unity(uint32_t logn) {
+  uint32_t e[8];
+  for (int i = 0; i < 8; i++) e[i] = FrParams::MOD(i);
+  e[0] -= 1;
+  for (uint32_t s = 0; s < logn; s++) {
+    for (int i = 0; i < 7; i++) e[i] = (e[i] >> 1) | (e[i + 1] << 31);
+    e[7] >>= 1;
+  }
+  return fr_pow_limbs(Fr::from_u64(5), e);
+}
+static uint32_t bitrev(uint32_t v, uint32_t bits) {
+  uint32_t r = 0;
+  for (uint32_t i = 0; i < bits; i++) r |= ((v >> i) & 1) << (bits - 1 - i);
+  return r;
+}
+static G1Affine g1_from_raw(const uint8_t* b) {
+  bool z = true;
+  for (int i = 0; i < 64; i++) z &= b[i] == 0;
+  if (z) return G1Affine::infinity();
+  return {Fq::from_bytes_be(b), Fq::from_bytes_be(b + 32)};
+}
+static G2Affine g2_from_raw(const uint8_t* b) {
+  bool z = true;
+  for (int i = 0; i < 128; i++) z &= b[i] == 0;
+  if (z) return G2Affine::infinity();
+  G2Affine p;
+  p.x.c1 = Fq::from_bytes_be(b);
+  p.x.c0 = Fq::from_bytes_be(b + 32);
+  p.y.c1 = Fq::from_bytes_be(b + 64);
+  p.y.c0 = Fq::from_bytes_be(b + 96);
+  return p;
+}
+static void g1_to_raw(const G1Affine& p, uint8_t* b) {
+  if (p.is_inf()) { memset(b, 0, 64); return; }
+  p.x.to_bytes_be(b);
+  p.y.to_bytes_be(b + 32);
+}
+static void g2_to_raw(const G2Affine& p, uint8_t* b) {
+  if (p.is_inf()) { memset(b, 0, 128); return; }
+  p.x.c1.to_bytes_be(b);
+  p.x.c0.to_bytes_be(b + 32);
+  p.y.c1.to_bytes_be(b + 64);
+  p.y.c0.to_bytes_be(b + 96);
+}
+template <class F>
+static Affine<F> host_add(const Affine<F>& a, const Affine<F>& b) {
+  XYZZ<F> x = XYZZ<F>::from_affine(a);
+  x.madd(b);
+  return x.to_affine();
+}
+static bool read_file(const char* path, std::vector<uint8_t>& out) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return false;
+  fseek(f, 0, SEEK_END);
+  long sz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  out.resize((size_t)sz);
+  bool ok = fread(out.data(), 1, out.size(), f) == out.size();
+  fclose(f);
+  return ok;
+}
+
+template <class T>
+static hipError_t dev_upload(T** dst, const std::vector<T>& src) {
+  *dst = nullptr;
+  size_t bytes = sizeof(T) * std::max<size_t>(src.size(), 1);
+  hipError_t e = hipMalloc((void**)dst, bytes);
+  if (e != hipSuccess) return e;
+  if (!src.empty()) e = hipMemcpy(*dst, src.data(), sizeof(T) * src.size(), hipMemcpyHostToDevice);
+  return e;
+}
+
+// -----------------------------------------------------------------------------------------------------
+// context / circuit objects
+// -----------------------------------------------------------------------------------------------------
+struct spp_ctx {
+  int device;
+  hipStream_t stream;
+  std::mutex mu;
+};
+
+template <class F>
+struct MsmSet {
+  uint32_t N = 0;
+  Affine<F>* table = nullptr;
+  uint32_t* rows = nullptr;
+  bool from_h = false;   // scalars come from the h array instead of the witness
+  XYZZ<F>* partial = nullptr;
+  XYZZ<F>* out = nullptr;
+  size_t partial_cap = 0;   // elements allocated in `partial`
+};
+
+struct spp_circuit {
+  spp_ctx* ctx = nullptr;
+  Circuit circ;
+  DevCircuit dc{};
+  uint32_t c_bits = 10, n = 0, logn = 0;
+  uint32_t pc_phase2 = 0, max_batch_div = 1;
+  uint32_t row_r = 0, row_s = 0, row_rs = 0, n_rows = 0;
+  uint64_t table_bytes = 0;
+  MsmSet<Fq> A, B1, K, Z, CB, CS;
+  MsmSet<Fq2> B2;
+  Fr *tw_fwd = nullptr, *tw_inv = nullptr, *coset_br = nullptr, *coset_inv_br = nullptr;
+  Fr zinv;
+  // device copies owned here
+  std::vector<void*> owned;
+  // workspace for `cap` proofs
+  size_t cap = 0, last_P = 0;
+  Fr *W = nullptr, *abc = nullptr, *scratch = nullptr;
+  G1Affine* commit_affine = nullptr;
+  uint8_t *d_inputs = nullptr, *d_rs = nullptr, *d_proofs = nullptr, *d_pws = nullptr;
+  uint32_t* d_status = nullptr;
+  std::vector<void*> ws_owned;
+  hipEvent_t ev[8] = {};
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> msm_ev;
+  size_t msm_ev_used = 0;
+  float last_ms[9] = {};
+};
+
+template <class T>
+static int own_upload(spp_circuit* c, T** dst, const std::vector<T>& src) {
+  HIP_TRY(dev_upload(dst, src));
+  c->owned.push_back((void*)*dst);
+  return 0;
+}
+static int upload_sparse(spp_circuit* c, const Circuit& circ, const Sparse& m, DevSparse* out) {
+  std::vector<uint32_t> wire(m.terms.size()), coeff(m.terms.size());
+  Fr one = Fr::one(), mone = Fr::one().neg();
+  for (size_t i = 0; i < m.terms.size(); i++) {
+    wire[i] = m.terms[i].wire;
+    uint32_t ci = m.terms[i].coeff;
+    uint32_t flag = 0;
+    if (circ.coeffs[ci] == one) flag = COEFF_ONE;
+    else if (circ.coeffs[ci] == mone) flag = COEFF_MINUS_ONE;
+    coeff[i] = ci | flag;
+  }
+  uint32_t *rp, *w, *co;
+  if (int e = own_upload(c, &rp, m.rowptr)) return e;
+  if (int e = own_upload(c, &w, wire)) return e;
+  if (int e = own_upload(c, &co, coeff)) return e;
+  out->rowptr = rp;
+  out->wire = w;
+  out->coeff = co;
+  return 0;
+}
+
+// builds the window table of `pts` on the device in chunks bounded by ~1.5 GiB of temporaries
+template <class F>
+static int build_table_chunked(spp_circuit* c, const std::vector<Affine<F>>& pts, uint32_t cbits, Affine<F>** table_out) {
+  hipStream_t st = c->ctx->stream;
+  const uint32_t Wn = msm_windows(cbits), E = 1u << (cbits - 1);
+  const size_t N = pts.size();
+  size_t table_elems = std::max<size_t>(N * Wn * E, 1);
+  Affine<F>* table;
+  HIP_TRY(hipMalloc((void**)&table, table_elems * sizeof(Affine<F>)));
+  c->owned.push_back(table);
+  c->table_bytes += table_elems * sizeof(Affine<F>);
+  *table_out = table;
+  if (N == 0) return 0;
+  const size_t per_base = (size_t)Wn * E * (sizeof(XYZZ<F>) + sizeof(F));
+  size_t chunk = std::max<size_t>(1, ((size_t)3 << 29) / per_base);
+  chunk = std::min(chunk, N);
+  Affine<F>* d_bases;
+  XYZZ<F>* tmp;
+  F* tmp_pre;
+  HIP_TRY(hipMalloc((void**)&d_bases, N * sizeof(Affine<F>)));
+  HIP_TRY(hipMemcpy(d_bases, pts.data(), N * sizeof(Affine<F>), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc((void**)&tmp, chunk * Wn * E * sizeof(XYZZ<F>)));
+  HIP_TRY(hipMalloc((void**)&tmp_pre, chunk * Wn * E * sizeof(F)));
+  for (size_t i0 = 0; i0 < N; i0 += chunk) {
+    uint32_t cnt = (uint32_t)std::min(chunk, N - i0);
+    launch_build_table<F>(st, d_bases + i0, cnt, cbits, table + i0 * Wn * E, tmp, tmp_pre);
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipGetLastError());
+  hipFree(d_bases);
+  hipFree(tmp);
+  hipFree(tmp_pre);
+  return 0;
+}
+
+template <class F>
+static int make_set(spp_circuit* c, MsmSet<F>* set, const std::vector<uint32_t>& rows, const std::vector<Affine<F>>& pts, bool from_h) {
+  set->N = (uint32_t)pts.size();
+  set->from_h = from_h;
+  if (int e = own_upload(c, &set->rows, rows)) return e;
+  return build_table_chunked<F>(c, pts, c->c_bits, &set->table);
+}
+
+// -----------------------------------------------------------------------------------------------------
+// circuit construction (host only)
+// -----------------------------------------------------------------------------------------------------
+extern "C" int spp_circuit_build(int circuit_id, const uint32_t* aux, const char* out_path, uint32_t* n_constraints) {
+  if (!out_path) return fail(SPP_ERR_BAD_INPUT, "out_path is NULL");
+  Circuit c;
+  if (circuit_id == SPP_CIRCUIT_WITHDRAW) {
+    c = build_withdraw_circuit(true);
+  } else if (circuit_id == SPP_CIRCUIT_AUDIT) {
+    if (!aux) return fail(SPP_ERR_BAD_INPUT, "audit circuit needs the RLWE public key (aux)");
+    c = build_audit_circuit(aux, aux + 1024, true);
+  } else {
+    return fail(SPP_ERR_BAD_INPUT, "unknown circuit id %d", circuit_id);
+  }
+  if (n_constraints) *n_constraints = c.n_constraints;
+  if (!c.save(out_path)) return fail(SPP_ERR_IO, "cannot write %s", out_path);
+  return SPP_OK;
+}
+
+// -----------------------------------------------------------------------------------------------------
+// context
+// -----------------------------------------------------------------------------------------------------
+extern "C" int spp_init(int device, spp_ctx** out) {
+  if (!out) return fail(SPP_ERR_BAD_INPUT, "out is NULL");
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return fail(SPP_ERR_NO_DEVICE, "no HIP device visible: libspp has no CPU fallback");
+  if (device < 0 || device >= count) return fail(SPP_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, count);
+  HIP_TRY(hipSetDevice(device));
+  spp_ctx* ctx = new spp_ctx();
+  ctx->device = device;
+  HIP_TRY(hipStreamCreate(&ctx->stream));
+  *out = ctx;
+  return SPP_OK;
+}
+extern "C" void spp_free_ctx(spp_ctx* ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+// -----------------------------------------------------------------------------------------------------
+// pk container
+// -----------------------------------------------------------------------------------------------------
+namespace {
+struct PkFile {
+  uint32_t circuit_id, n_wires, domain_log, n_public, challenge_wire;
+  G1Affine alpha1, beta1, delta1;
+  G2Affine beta2, delta2;
+  std::vector<uint32_t> A_w, B1_w, B2_w, K_w, CB_w, CS_w;
+  std::vector<G1Affine> A, B1, K, Z, CB, CS;
+  std::vector<G2Affine> B2;
+};
+struct Rd {
+  const uint8_t* p;
+  const uint8_t* end;
+  bool ok = true;
+  uint32_t u32() {
+    if (p + 4 > end) { ok = false; return 0; }
+    uint32_t v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+    p += 4;
+    return v;
+  }
+  const uint8_t* take(size_t n) {
+    if (p + n > end) { ok = false; return nullptr; }
+    const uint8_t* q = p;
+    p += n;
+    return q;
+  }
+};
+bool rd_g1_section(Rd& r, std::vector<uint32_t>* wires, std::vector<G1Affine>& pts) {
+  uint32_t n = r.u32();
+  if (!r.ok || (size_t)n * 64 > (size_t)(r.end - r.p)) return false;
+  if (wires) {
+    wires->resize(n);
+    for (auto& w : *wires) w = r.u32();
+  }
+  pts.resize(n);
+  for (auto& pt : pts) {
+    const uint8_t* b = r.take(64);
+    if (!b) return false;
+    pt = g1_from_raw(b);
+  }
+  return r.ok;
+}
+bool parse_pk(const std::vector<uint8_t>& buf, PkFile& k) {
+  Rd r{buf.data(), buf.data() + buf.size()};
+  if (r.u32() != 0x4b505053u || r.u32() != 1) return false;
+  k.circuit_id = r.u32(); k.n_wires = r.u32(); k.domain_log = r.u32(); k.n_public = r.u32(); k.challenge_wire = r.u32();
+  const uint8_t* b;
+  if (!(b = r.take(64))) return false; k.alpha1 = g1_from_raw(b);
+  if (!(b = r.take(64))) return false; k.beta1 = g1_from_raw(b);
+  if (!(b = r.take(64))) return false; k.delta1 = g1_from_raw(b);
+  if (!(b = r.take(128))) return false; k.beta2 = g2_from_raw(b);
+  if (!(b = r.take(128))) return false; k.delta2 = g2_from_raw(b);
+  if (!rd_g1_section(r, &k.A_w, k.A)) return false;
+  if (!rd_g1_section(r, &k.B1_w, k.B1)) return false;
+  uint32_t n2 = r.u32();
+  if (!r.ok || (size_t)n2 * 128 > (size_t)(r.end - r.p)) return false;
+  k.B2_w.resize(n2);
+  for (auto& w : k.B2_w) w = r.u32();
+  k.B2.resize(n2);
+  for (auto& pt : k.B2) {
+    if (!(b = r.take(128))) return false;
+    pt = g2_from_raw(b);
+  }
+  if (!rd_g1_section(r, &k.K_w, k.K)) return false;
+  if (!rd_g1_section(r, nullptr, k.Z)) return false;
+  if (!rd_g1_section(r, &k.CB_w, k.CB)) return false;
+  if (!rd_g1_section(r, &k.CS_w, k.CS)) return false;
+  return r.ok && r.p == r.end;
+}
+}  // namespace
+
+// merge `extra` into the entry of `wire` (or append one)
+template <class F>
+static void merge_point(std::vector<uint32_t>& wires, std::vector<Affine<F>>& pts, uint32_t wire, const Affine<F>& extra) {
+  for (size_t i = 0; i < wires.size(); i++)
+    if (wires[i] == wire) {
+      pts[i] = host_add(pts[i], extra);
+      return;
+    }
+  wires.push_back(wire);
+  pts.push_back(extra);
+}
+
+extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const char* pk_path, int window_bits, spp_circuit** out) {
+  if (!ctx || !circuit_path || !pk_path || !out) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  if (window_bits == 0) window_bits = 10;
+  if (window_bits < 4 || window_bits > 16) return fail(SPP_ERR_BAD_INPUT, "window_bits %d outside [4,16]", window_bits);
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_TRY(hipSetDevice(ctx->device));
+  spp_circuit* c = new spp_circuit();
+  c->ctx = ctx;
+  c->c_bits = (uint32_t)window_bits;
+  if (!c->circ.load(circuit_path)) { delete c; return fail(SPP_ERR_IO, "cannot read circuit %s", circuit_path); }
+  std::vector<uint8_t> pkbuf;
+  PkFile pk;
+  if (!read_file(pk_path, pkbuf)) { delete c; return fail(SPP_ERR_IO, "cannot read proving key %s", pk_path); }
+  if (!parse_pk(pkbuf, pk)) { delete c; return fail(SPP_ERR_FORMAT, "malformed proving key %s", pk_path); }
+  const Circuit& circ = c->circ;
+  if (pk.circuit_id != circ.id || pk.n_wires != circ.n_wires || pk.domain_log != circ.domain_log) {
+    delete c;
+    return fail(SPP_ERR_FORMAT, "proving key does not match the circuit");
+  }
+  c->logn = circ.domain_log;
+  c->n = 1u << c->logn;
+  c->row_r = circ.n_wires;
+  c->row_s = circ.n_wires + 1;
+  c->row_rs = circ.n_wires + 2;
+  c->n_rows = circ.n_wires + 3;
+
+  // ---- R1CS + program + hash constants ----
+  int e;
+  if ((e = upload_sparse(c, circ, circ.A, &c->dc.A)) || (e = upload_sparse(c, circ, circ.B, &c->dc.B)) ||
+      (e = upload_sparse(c, circ, circ.C, &c->dc.C)) || (e = upload_sparse(c, circ, circ.H, &c->dc.H)))
+    return e;
+  Fr* d_coeffs;
+  uint32_t* d_prog;
+  if ((e = own_upload(c, &d_coeffs, circ.coeffs)) || (e = own_upload(c, &d_prog, circ.program))) return e;
+  c->dc.coeffs = d_coeffs;
+  c->dc.program = d_prog;
+  c->dc.n_wires = circ.n_wires;
+  c->dc.n_constraints = circ.n_constraints;
+  c->dc.n_public = circ.n_public;
+  c->dc.n_inputs = circ.n_inputs();
+  c->dc.challenge_wire = circ.challenge_wire;
+  {
+    auto flat = [](const PoseidonParams& pp) {
+      std::vector<Fr> m;
+      for (auto& row : pp.mds)
+        for (auto& v : row) m.push_back(v);
+      return m;
+    };
+    const PoseidonParams& p3 = poseidon_params(3);
+    const PoseidonParams& p5 = poseidon_params(5);
+    const Poseidon2Params& p2 = poseidon2_params();
+    Fr *a, *b, *cc, *d, *f, *g;
+    std::vector<Fr> mu(p2.mu, p2.mu + 4);
+    if ((e = own_upload(c, &a, p3.rc)) || (e = own_upload(c, &b, flat(p3))) || (e = own_upload(c, &cc, p5.rc)) ||
+        (e = own_upload(c, &d, flat(p5))) || (e = own_upload(c, &f, p2.rc)) || (e = own_upload(c, &g, mu)))
+      return e;
+    c->dc.pos3_rc = a; c->dc.pos3_mds = b; c->dc.pos5_rc = cc; c->dc.pos5_mds = d; c->dc.p2_rc = f; c->dc.p2_mu = g;
+  }
+  // program scan: phase-2 entry and largest batch division
+  {
+    const auto& pr = circ.program;
+    size_t pc = 0;
+    c->pc_phase2 = 0;
+    while (pc < pr.size() && pr[pc] != OP_END) {
+      switch (pr[pc]) {
+        case OP_SOLVE_C: case OP_SOLVE_A: pc += 2; break;
+        case OP_BATCH_DIV: c->max_batch_div = std::max(c->max_batch_div, pr[pc + 2]); pc += 3; break;
+        case OP_BITS: case OP_LIMBS8: case OP_COUNT8: case OP_POSEIDON: pc += 4; break;
+        case OP_POSEIDON2: pc += 3; break;
+        case OP_COMMIT: pc += 1; c->pc_phase2 = (uint32_t)pc; break;
+        default: return fail(SPP_ERR_FORMAT, "bad opcode %u in solver program", pr[pc]);
+      }
+    }
+  }
+
+  // ---- NTT tables ----
+  {
+    const uint32_t n = c->n, logn = c->logn;
+    Fr w = fr_root_of_unity(logn), wi = w.inv();
+    std::vector<Fr> tf(n / 2), ti(n / 2), cb(n), cib(n);
+    Fr a = Fr::one(), b = Fr::one();
+    for (uint32_t k = 0; k < n / 2; k++) {
+      tf[k] = a;
+      ti[k] = b;
+      a = a * w;
+      b = b * wi;
+    }
+    Fr g = Fr::from_u64(5), gi = g.inv(), ninv = Fr::from_u64(n).inv();
+    std::vector<Fr> gp(n), gip(n);
+    Fr x = ninv, y = ninv;
+    for (uint32_t i = 0; i < n; i++) {
+      gp[i] = x;
+      gip[i] = y;
+      x = x * g;
+      y = y * gi;
+    }
+    for (uint32_t pos = 0; pos < n; pos++) {
+      uint32_t i = bitrev(pos, logn);
+      cb[pos] = gp[i];
+      cib[pos] = gip[i];
+    }
+    if ((e = own_upload(c, &c->tw_fwd, tf)) || (e = own_upload(c, &c->tw_inv, ti)) || (e = own_upload(c, &c->coset_br, cb)) ||
+        (e = own_upload(c, &c->coset_inv_br, cib)))
+      return e;
+    Fr gn = g.pow_u64(n);
+    c->zinv = (gn - Fr::one()).inv();
+  }
+
+  // ---- MSM sets ----
+  {
+    std::vector<uint32_t> w = pk.A_w;
+    std::vector<G1Affine> p = pk.A;
+    merge_point(w, p, 0u, pk.alpha1);
+    w.push_back(c->row_r); p.push_back(pk.delta1);
+    if ((e = make_set(c, &c->A, w, p, false))) return e;
+  }
+  {
+    std::vector<uint32_t> w = pk.B1_w;
+    std::vector<G1Affine> p = pk.B1;
+    merge_point(w, p, 0u, pk.beta1);
+    w.push_back(c->row_s); p.push_back(pk.delta1);
+    if ((e = make_set(c, &c->B1, w, p, false))) return e;
+  }
+  {
+    std::vector<uint32_t> w = pk.B2_w;
+    std::vector<G2Affine> p = pk.B2;
+    merge_point(w, p, 0u, pk.beta2);
+    w.push_back(c->row_s); p.push_back(pk.delta2);
+    if ((e = make_set(c, &c->B2, w, p, false))) return e;
+  }
+  {
+    std::vector<uint32_t> w = pk.K_w;
+    std::vector<G1Affine> p = pk.K;
+    w.push_back(c->row_rs); p.push_back(pk.delta1.neg());
+    if ((e = make_set(c, &c->K, w, p, false))) return e;
+  }
+  {
+    // h comes out of the last DIF pass in bit-reversed order: row `pos` holds h_{bitrev(pos)}
+    if (pk.Z.size() != (size_t)c->n - 1) return fail(SPP_ERR_FORMAT, "Z section has %zu points, expected %u", pk.Z.size(), c->n - 1);
+    std::vector<uint32_t> w;
+    std::vector<G1Affine> p;
+    for (uint32_t pos = 0; pos < c->n; pos++) {
+      uint32_t i = bitrev(pos, c->logn);
+      if (i == c->n - 1) continue;
+      w.push_back(pos);
+      p.push_back(pk.Z[i]);
+    }
+    if ((e = make_set(c, &c->Z, w, p, true))) return e;
+  }
+  if ((e = make_set(c, &c->CB, pk.CB_w, pk.CB, false))) return e;
+  if ((e = make_set(c, &c->CS, pk.CS_w, pk.CS, false))) return e;
+
+  for (auto& evt : c->ev) HIP_TRY(hipEventCreate(&evt));
+  c->msm_ev.resize(8);
+  for (auto& pr : c->msm_ev) {
+    HIP_TRY(hipEventCreate(&pr.first));
+    HIP_TRY(hipEventCreate(&pr.second));
+  }
+  *out = c;
+  return SPP_OK;
+}
+
+static void free_workspace(spp_circuit* c) {
+  for (void* p : c->ws_owned) hipFree(p);
+  c->ws_owned.clear();
+  c->cap = 0;
+}
+extern "C" void spp_free_circuit(spp_circuit* c) {
+  if (!c) return;
+  hipSetDevice(c->ctx->device);
+  hipStreamSynchronize(c->ctx->stream);
+  free_workspace(c);
+  for (void* p : c->owned) hipFree(p);
+  for (auto& evt : c->ev) if (evt) hipEventDestroy(evt);
+  for (auto& pr : c->msm_ev) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+  delete c;
+}
+extern "C" int spp_circuit_info(const spp_circuit* c, uint32_t info[8]) {
+  if (!c || !info) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  info[0] = c->circ.id; info[1] = c->circ.n_public - 1; info[2] = c->circ.n_secret; info[3] = c->circ.n_wires;
+  info[4] = c->circ.n_constraints; info[5] = c->circ.domain_log; info[6] = c->circ.n_inputs(); info[7] = c->c_bits;
+  return SPP_OK;
+}
+extern "C" uint64_t spp_circuit_table_bytes(const spp_circuit* c) { return c ? c->table_bytes : 0; }
+
+template <class T>
+static int ws_alloc(spp_circuit* c, T** p, size_t count) {
+  HIP_TRY(hipMalloc((void**)p, sizeof(T) * std::max<size_t>(count, 1)));
+  c->ws_owned.push_back((void*)*p);
+  return 0;
+}
+template <class F>
+static int ws_set(spp_circuit* c, MsmSet<F>* s, size_t P) {
+  // S(P')*P' <= min(target + P', ceil(N/4)*P') for every P' <= P
+  size_t max_s = std::max<size_t>((s->N + 3) / 4, 1);
+  s->partial_cap = std::min<size_t>((size_t)256 * 4 * 4 * 64 + P, max_s * P);
+  s->partial_cap = std::max<size_t>(s->partial_cap, (size_t)msm_slices(s->N, (uint32_t)P) * P);
+  int e;
+  if ((e = ws_alloc(c, &s->partial, s->partial_cap))) return e;
+  return ws_alloc(c, &s->out, P);
+}
+static int ensure_workspace(spp_circuit* c, size_t P) {
+  if (P <= c->cap) return 0;
+  free_workspace(c);
+  int e;
+  const size_t npub = c->circ.n_public - 1;
+  if ((e = ws_alloc(c, &c->W, (size_t)c->n_rows * P)) || (e = ws_alloc(c, &c->abc, (size_t)3 * c->n * P)) ||
+      (e = ws_alloc(c, &c->scratch, (size_t)c->max_batch_div * P)) || (e = ws_alloc(c, &c->commit_affine, P)) ||
+      (e = ws_alloc(c, &c->d_inputs, (size_t)c->circ.n_inputs() * 32 * P)) || (e = ws_alloc(c, &c->d_rs, 64 * P)) ||
+      (e = ws_alloc(c, &c->d_proofs, (size_t)SPP_PROOF_LEN * P)) || (e = ws_alloc(c, &c->d_pws, (12 + 32 * npub) * P)) ||
+      (e = ws_alloc(c, &c->d_status, P)))
+    return e;
+  if ((e = ws_set(c, &c->A, P)) || (e = ws_set(c, &c->B1, P)) || (e = ws_set(c, &c->B2, P)) || (e = ws_set(c, &c->K, P)) ||
+      (e = ws_set(c, &c->Z, P)) || (e = ws_set(c, &c->CB, P)) || (e = ws_set(c, &c->CS, P)))
+    return e;
+  c->cap = P;
+  return 0;
+}
+
+template <class F>
+static void run_msm(spp_circuit* c, MsmSet<F>& s, uint32_t P, bool timed) {
+  hipStream_t st = c->ctx->stream;
+  const Fr* scal = s.from_h ? c->abc : c->W;
+  uint32_t S = msm_slices(s.N, P);
+  while (S > 1 && (size_t)S * P > s.partial_cap) S--;  // never exceed the allocated partial buffer
+  std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+  if (timed && c->msm_ev_used < c->msm_ev.size()) ev = &c->msm_ev[c->msm_ev_used++];
+  if (ev) hipEventRecord(ev->first, st);
+  launch_msm_accumulate<F>(st, s.table, s.rows, scal, s.partial, s.N, P, c->c_bits, S);
+  if (ev) hipEventRecord(ev->second, st);
+  launch_msm_reduce<F>(st, s.partial, s.out, P, s.N ? S : 0);
+}
+
+static int prove_on_device(spp_circuit* c, uint32_t P, const uint8_t* d_inputs, const uint8_t* d_rs, uint8_t* d_proofs, uint8_t* d_pws,
+                           uint32_t* d_status) {
+  hipStream_t st = c->ctx->stream;
+  const Circuit& circ = c->circ;
+  const uint32_t n = c->n;
+  c->msm_ev_used = 0;
+  c->last_P = P;
+  HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(uint32_t) * P, st));
+  hipEventRecord(c->ev[0], st);
+  // 1. inputs, solver phase 1, commitment, challenge, solver phase 2
+  launch_load_inputs(st, d_inputs, d_rs, c->W, circ.n_inputs(), circ.n_wires, P);
+  launch_solve(st, c->dc, c->W, c->scratch, 0, P);
+  run_msm(c, c->CB, P, true);
+  launch_challenge(st, c->CB.out, c->W, circ.challenge_wire, P, c->commit_affine, d_status);
+  launch_solve(st, c->dc, c->W, c->scratch, c->pc_phase2, P);
+  hipEventRecord(c->ev[1], st);
+  // 2. constraint evaluations + satisfaction check
+  launch_spmv_check(st, c->dc, c->W, c->abc, n, P, d_status);
+  hipEventRecord(c->ev[2], st);
+  // 3. h = (a*b - c)/Z  (coefficients land bit-reversed in the a-slot of abc)
+  const size_t bs = (size_t)n * P;
+  launch_ntt(st, c->abc, c->logn, P, c->tw_inv, true, 3, bs);
+  launch_scale_rows(st, c->abc, c->coset_br, n, P, 3, bs);
+  launch_ntt(st, c->abc, c->logn, P, c->tw_fwd, false, 3, bs);
+  launch_qap_pointwise(st, c->abc, n, P, c->zinv);
+  launch_ntt(st, c->abc, c->logn, P, c->tw_inv, true, 1, bs);
+  launch_scale_rows(st, c->abc, c->coset_inv_br, n, P, 1, bs);
+  hipEventRecord(c->ev[3], st);
+  // 4. MSMs
+  run_msm(c, c->A, P, true);
+  run_msm(c, c->B1, P, true);
+  run_msm(c, c->K, P, true);
+  run_msm(c, c->Z, P, true);
+  run_msm(c, c->CS, P, true);
+  hipEventRecord(c->ev[4], st);
+  run_msm(c, c->B2, P, false);
+  hipEventRecord(c->ev[5], st);
+  // 5. assembly
+  AssembleArgs a;
+  a.mA = c->A.out; a.mB1 = c->B1.out; a.mB2 = c->B2.out; a.mK = c->K.out; a.mZ = c->Z.out; a.mPok = c->CS.out;
+  a.commit_affine = c->commit_affine;
+  a.W = c->W; a.row_r = c->row_r; a.row_s = c->row_s; a.n_public = circ.n_public;
+  a.proofs = d_proofs; a.pws = d_pws; a.P = P;
+  launch_assemble(st, a);
+  hipEventRecord(c->ev[6], st);
+  HIP_TRY(hipGetLastError());
+  return SPP_OK;
+}
+
+extern "C" int spp_prove_batch_device(spp_circuit* c, size_t count, const void* d_inputs, const void* d_rs, void* d_proofs, void* d_pws,
+                                      void* d_status) {
+  if (!c || !d_inputs || !d_rs || !d_proofs || !d_pws || !d_status) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  if (count == 0) return SPP_OK;
+  if (count > (1u << 20)) return fail(SPP_ERR_BAD_INPUT, "batch too large");
+  std::lock_guard<std::mutex> lk(c->ctx->mu);
+  HIP_TRY(hipSetDevice(c->ctx->device));
+  if (int e = ensure_workspace(c, count)) return e;
+  return prove_on_device(c, (uint32_t)count, (const uint8_t*)d_inputs, (const uint8_t*)d_rs, (uint8_t*)d_proofs, (uint8_t*)d_pws,
+                         (uint32_t*)d_status);
+}
+extern "C" int spp_sync(spp_circuit* c) {
+  if (!c) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  HIP_TRY(hipSetDevice(c->ctx->device));
+  HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+  return SPP_OK;
+}
+extern "C" int spp_last_timings(spp_circuit* c, float ms[9]) {
+  if (!c || !ms) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  HIP_TRY(hipSetDevice(c->ctx->device));
+  HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+  for (int i = 0; i < 6; i++) {
+    float t = 0;
+    HIP_TRY(hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]));
+    ms[i] = t;
+  }
+  float tot = 0;
+  HIP_TRY(hipEventElapsedTime(&tot, c->ev[0], c->ev[6]));
+  ms[6] = tot;
+  float sum = 0;
+  for (size_t i = 0; i < c->msm_ev_used; i++) {
+    float t = 0;
+    HIP_TRY(hipEventElapsedTime(&t, c->msm_ev[i].first, c->msm_ev[i].second));
+    sum += t;
+  }
+  ms[7] = c->msm_ev_used ? sum / (float)c->msm_ev_used : 0.f;
+  ms[8] = (float)c->msm_ev_used;
+  return SPP_OK;
+}
+
+extern "C" int spp_prove_batch(spp_circuit* c, size_t count, const uint8_t* inputs, const uint8_t* rs, uint8_t* proofs, uint8_t* pws,
+                               int32_t* status) {
+  if (!c || !inputs || !proofs || !pws) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  if (count == 0) return SPP_OK;
+  std::vector<uint8_t> rnd;
+  if (!rs) {
+    rnd.resize(64 * count);
+    FILE* f = fopen("/dev/urandom", "rb");
+    if (!f || fread(rnd.data(), 1, rnd.size(), f) != rnd.size()) {
+      if (f) fclose(f);
+      return fail(SPP_ERR_IO, "cannot read /dev/urandom");
+    }
+    fclose(f);
+    rs = rnd.data();
+  }
+  std::vector<uint32_t> st(count);
+  {
+    std::lock_guard<std::mutex> lk(c->ctx->mu);
+    HIP_TRY(hipSetDevice(c->ctx->device));
+    if (int e = ensure_workspace(c, count)) return e;
+    hipStream_t s = c->ctx->stream;
+    const size_t nin = c->circ.n_inputs(), npub = c->circ.n_public - 1;
+    HIP_TRY(hipMemcpyAsync(c->d_inputs, inputs, nin * 32 * count, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->d_rs, rs, 64 * count, hipMemcpyHostToDevice, s));
+    if (int e = prove_on_device(c, (uint32_t)count, c->d_inputs, c->d_rs, c->d_proofs, c->d_pws, c->d_status)) return e;
+    HIP_TRY(hipMemcpyAsync(proofs, c->d_proofs, (size_t)SPP_PROOF_LEN * count, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(pws, c->d_pws, (12 + 32 * npub) * count, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(st.data(), c->d_status, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  int rc = SPP_OK;
+  for (size_t i = 0; i < count; i++) {
+    int32_t v = st[i] ? SPP_ERR_UNSAT : SPP_OK;
+    if (status) status[i] = v;
+    if (v && rc == SPP_OK) rc = fail(SPP_ERR_UNSAT, "proof %zu: inputs do not satisfy the circuit", i);
+    if (v) memset(proofs + (size_t)SPP_PROOF_LEN * i, 0, SPP_PROOF_LEN);
+  }
+  return rc;
+}
+
+extern "C" int spp_prove_withdraw(spp_circuit* c, const spp_withdraw_inputs* in, const uint8_t rs_seed[64], uint8_t proof[SPP_PROOF_LEN],
+                                  uint8_t pw[SPP_WITHDRAW_PW_LEN]) {
+  if (!c || !in || !proof || !pw) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  if (c->circ.id != SPP_CIRCUIT_WITHDRAW) return fail(SPP_ERR_BAD_INPUT, "not a withdraw circuit");
+  std::vector<uint8_t> buf(26 * 32, 0);
+  auto put = [&](int i, const uint8_t* v) { memcpy(buf.data() + 32 * i, v, 32); };
+  auto put64 = [&](int i, uint64_t v) { for (int k = 0; k < 8; k++) buf[32 * i + 31 - k] = (uint8_t)(v >> (8 * k)); };
+  put(0, in->root); put(1, in->nullifier); put(2, in->recipient); put64(3, in->amount); put(4, in->wa_commitment);
+  put(5, in->secret_key); put(6, in->owner_x); put(7, in->owner_y); put(8, in->randomness); put64(9, in->index);
+  for (int i = 0; i < SPP_TREE_DEPTH; i++) put(10 + i, in->siblings[i]);
+  int32_t st = 0;
+  return spp_prove_batch(c, 1, buf.data(), rs_seed, proof, pw, &st);
+}
+
+extern "C" int spp_debug_witness(spp_circuit* c, uint8_t* out, size_t n_wires) {
+  if (!c || !out) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  if (c->cap == 0) return fail(SPP_ERR_BAD_INPUT, "no batch has been proved yet");
+  std::lock_guard<std::mutex> lk(c->ctx->mu);
+  HIP_TRY(hipSetDevice(c->ctx->device));
+  HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+  size_t P = c->last_P;   // column 0 of W at the stride of the last batch
+  std::vector<Fr> col(std::min<size_t>(n_wires, c->circ.n_wires));
+  for (size_t i = 0; i < col.size(); i++) HIP_TRY(hipMemcpy(&col[i], c->W + i * P, sizeof(Fr), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < col.size(); i++) col[i].to_bytes_be(out + 32 * i);
+  return SPP_OK;
+}
+
+// -----------------------------------------------------------------------------------------------------
+// setup on the GPU
+// -----------------------------------------------------------------------------------------------------
+static void wr32(std::vector<uint8_t>& o, uint32_t v) { for (int i = 0; i < 4; i++) o.push_back((uint8_t)(v >> (8 * i))); }
+static void wr32be(std::vector<uint8_t>& o, uint32_t v) { for (int i = 3; i >= 0; i--) o.push_back((uint8_t)(v >> (8 * i))); }
+static void wr_g1(std::vector<uint8_t>& o, const G1Affine& p) { uint8_t b[64]; g1_to_raw(p, b); o.insert(o.end(), b, b + 64); }
+static void wr_g2(std::vector<uint8_t>& o, const G2Affine& p) { uint8_t b[128]; g2_to_raw(p, b); o.insert(o.end(), b, b + 128); }
+static bool write_file(const char* path, const std::vector<uint8_t>& o) {
+  FILE* f = fopen(path, "wb");
+  if (!f) return false;
+  bool ok = fwrite(o.data(), 1, o.size(), f) == o.size();
+  fclose(f);
+  return ok;
+}
+
+extern "C" int spp_setup(spp_ctx* ctx, const char* circuit_path, const uint8_t seed[32], const char* pk_path, const char* vk_path) {
+  if (!ctx || !circuit_path || !seed || !pk_path || !vk_path) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  Circuit circ;
+  if (!circ.load(circuit_path)) return fail(SPP_ERR_IO, "cannot read circuit %s", circuit_path);
+  // toxic waste = hash_to_fr(seed, "spp-groth16-setup-v1", 7)
+  Fr tox[7];
+  {
+    const char* dst = "spp-groth16-setup-v1";
+    uint8_t u[7 * 48];
+    expand_message_xmd(seed, 32, (const uint8_t*)dst, strlen(dst), u, sizeof u);
+    for (int i = 0; i < 7; i++) {
+      uint32_t w[12];
+      for (int k = 0; k < 12; k++) {
+        const uint8_t* q = u + 48 * i + 4 * k;
+        w[k] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
+      }
+      tox[i] = fr_from_wide48(w);
+    }
+  }
+  const Fr tau = tox[0], alpha = tox[1], beta = tox[2], gamma = tox[3], delta = tox[4], sigma = tox[5], rho = tox[6];
+  const uint32_t logn = circ.domain_log, n = 1u << logn, W = circ.n_wires;
+  // Lagrange basis at tau
+  std::vector<Fr> L(n), den(n), pre(n);
+  {
+    Fr omega = fr_root_of_unity(logn);
+    Fr zt = tau.pow_u64(n) - Fr::one();
+    Fr scale = zt * Fr::from_u64(n).inv();
+    Fr wk = Fr::one(), acc = Fr::one();
+    for (uint32_t k = 0; k < n; k++) {
+      den[k] = tau - wk;
+      pre[k] = acc;
+      acc = acc * den[k];
+      L[k] = wk;
+      wk = wk * omega;
+    }
+    Fr ia = acc.inv();
+    for (uint32_t k = n; k-- > 0;) {
+      Fr di = ia * pre[k];
+      ia = ia * den[k];
+      L[k] = L[k] * di * scale;
+    }
+  }
+  std::vector<Fr> aw(W, Fr::zero()), bw(W, Fr::zero()), cw(W, Fr::zero());
+  {
+    const Sparse* M[3] = {&circ.A, &circ.B, &circ.C};
+    std::vector<Fr>* O[3] = {&aw, &bw, &cw};
+    for (int m = 0; m < 3; m++)
+      for (uint32_t k = 0; k < circ.n_constraints; k++)
+        for (uint32_t i = M[m]->rowptr[k]; i < M[m]->rowptr[k + 1]; i++) {
+          const Term& t = M[m]->terms[i];
+          (*O[m])[t.wire] = (*O[m])[t.wire] + circ.coeffs[t.coeff] * L[k];
+        }
+  }
+  std::vector<uint8_t> cls(W, 0);
+  for (uint32_t j = 0; j < circ.n_public; j++) cls[j] = 1;
+  cls[circ.challenge_wire] = 1;
+  for (uint32_t w : circ.committed) cls[w] = 2;
+  const Fr gi = gamma.inv(), di = delta.inv(), sigi = sigma.inv();
+  // scalar vectors, one fixed-base multiplication each:
+  //   G1: [A(W) | B1(W) | K(W) | S(W) | Z(n-1) | alpha beta delta]    G2: [B2(W) | beta gamma delta rho -rho/sigma]
+  std::vector<Fr> s1, s2;
+  s1.reserve((size_t)4 * W + n + 3);
+  for (uint32_t j = 0; j < W; j++) s1.push_back(aw[j]);
+  for (uint32_t j = 0; j < W; j++) s1.push_back(bw[j]);
+  std::vector<Fr> kk(W);
+  for (uint32_t j = 0; j < W; j++) kk[j] = (beta * aw[j] + alpha * bw[j] + cw[j]) * (cls[j] ? gi : di);
+  for (uint32_t j = 0; j < W; j++) s1.push_back(kk[j]);
+  for (uint32_t j = 0; j < W; j++) s1.push_back(cls[j] == 2 ? kk[j] * sigma : Fr::zero());
+  {
+    Fr zt = tau.pow_u64(n) - Fr::one();
+    Fr pw = zt * di;
+    for (uint32_t i = 0; i + 1 < n; i++) {
+      s1.push_back(pw);
+      pw = pw * tau;
+    }
+  }
+  s1.push_back(alpha); s1.push_back(beta); s1.push_back(delta);
+  for (uint32_t j = 0; j < W; j++) s2.push_back(bw[j]);
+  s2.push_back(beta); s2.push_back(gamma); s2.push_back(delta); s2.push_back(rho); s2.push_back((rho * sigi).neg());
+
+  // generator tables (c = 8) and the batched fixed-base multiplications on the GPU
+  const uint32_t cb = 8, Wn = msm_windows(cb), E = 1u << (cb - 1);
+  G1Affine g1{Fq::from_u64(1), Fq::from_u64(2)};
+  auto fq_dec = [](const char* dec) {
+    Fq acc = Fq::zero(), ten = Fq::from_u64(10);
+    for (const char* ch = dec; *ch; ch++) acc = acc * ten + Fq::from_u64((uint64_t)(*ch - '0'));
+    return acc;
+  };
+  G2Affine g2;
+  g2.x.c0 = fq_dec("10857046999023057135944570762232829481370756359578518086990519993285655852781");
+  g2.x.c1 = fq_dec("11559732032986387107991004021392285783925812861821192530917403151452391805634");
+  g2.y.c0 = fq_dec("8495653923123431417604973247489272438418190587263600148770280649306958101930");
+  g2.y.c1 = fq_dec("4082367875863433681332203403145435568316851327593401208105741076214120093531");
+  G1Affine *d_g1, *t1, *o1;
+  G2Affine *d_g2, *t2, *o2;
+  G1XYZZ* tmp1;
+  G2XYZZ* tmp2;
+  Fq* pre1;
+  Fq2* pre2;
+  Fr *d_s1, *d_s2;
+  HIP_TRY(hipMalloc((void**)&d_g1, sizeof g1)); HIP_TRY(hipMemcpy(d_g1, &g1, sizeof g1, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc((void**)&d_g2, sizeof g2)); HIP_TRY(hipMemcpy(d_g2, &g2, sizeof g2, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc((void**)&t1, sizeof(G1Affine) * Wn * E)); HIP_TRY(hipMalloc((void**)&t2, sizeof(G2Affine) * Wn * E));
+  HIP_TRY(hipMalloc((void**)&tmp1, sizeof(G1XYZZ) * Wn * E)); HIP_TRY(hipMalloc((void**)&tmp2, sizeof(G2XYZZ) * Wn * E));
+  HIP_TRY(hipMalloc((void**)&pre1, sizeof(Fq) * Wn * E)); HIP_TRY(hipMalloc((void**)&pre2, sizeof(Fq2) * Wn * E));
+  HIP_TRY(hipMalloc((void**)&d_s1, sizeof(Fr) * s1.size())); HIP_TRY(hipMalloc((void**)&d_s2, sizeof(Fr) * s2.size()));
+  HIP_TRY(hipMalloc((void**)&o1, sizeof(G1Affine) * s1.size())); HIP_TRY(hipMalloc((void**)&o2, sizeof(G2Affine) * s2.size()));
+  HIP_TRY(hipMemcpyAsync(d_s1, s1.data(), sizeof(Fr) * s1.size(), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_s2, s2.data(), sizeof(Fr) * s2.size(), hipMemcpyHostToDevice, st));
+  launch_build_table<Fq>(st, d_g1, 1, cb, t1, tmp1, pre1);
+  launch_build_table<Fq2>(st, d_g2, 1, cb, t2, tmp2, pre2);
+  launch_fixed_base_mul<Fq>(st, t1, cb, d_s1, (uint32_t)s1.size(), o1, nullptr);
+  launch_fixed_base_mul<Fq2>(st, t2, cb, d_s2, (uint32_t)s2.size(), o2, nullptr);
+  std::vector<G1Affine> p1(s1.size());
+  std::vector<G2Affine> p2(s2.size());
+  HIP_TRY(hipMemcpyAsync(p1.data(), o1, sizeof(G1Affine) * p1.size(), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(p2.data(), o2, sizeof(G2Affine) * p2.size(), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipGetLastError());
+  for (void* q : {(void*)d_g1, (void*)d_g2, (void*)t1, (void*)t2, (void*)tmp1, (void*)tmp2, (void*)pre1, (void*)pre2, (void*)d_s1,
+                  (void*)d_s2, (void*)o1, (void*)o2})
+    hipFree(q);
+
+  const G1Affine* pA = p1.data();
+  const G1Affine* pB1 = pA + W;
+  const G1Affine* pK = pB1 + W;
+  const G1Affine* pS = pK + W;
+  const G1Affine* pZ = pS + W;
+  const G1Affine* pC = pZ + (n - 1);
+  const G2Affine* pB2 = p2.data();
+  const G2Affine* pC2 = pB2 + W;
+
+  std::vector<uint8_t> o;
+  wr32(o, 0x4b505053u); wr32(o, 1);
+  wr32(o, circ.id); wr32(o, W); wr32(o, logn); wr32(o, circ.n_public); wr32(o, circ.challenge_wire);
+  wr_g1(o, pC[0]); wr_g1(o, pC[1]); wr_g1(o, pC[2]); wr_g2(o, pC2[0]); wr_g2(o, pC2[2]);
+  auto sec1 = [&](const G1Affine* pts, auto pred) {
+    uint32_t cnt = 0;
+    for (uint32_t j = 0; j < W; j++) cnt += pred(j) ? 1 : 0;
+    wr32(o, cnt);
+    for (uint32_t j = 0; j < W; j++) if (pred(j)) wr32(o, j);
+    for (uint32_t j = 0; j < W; j++) if (pred(j)) wr_g1(o, pts[j]);
+  };
+  sec1(pA, [&](uint32_t j) { return !pA[j].is_inf(); });
+  sec1(pB1, [&](uint32_t j) { return !pB1[j].is_inf(); });
+  {
+    uint32_t cnt = 0;
+    for (uint32_t j = 0; j < W; j++) cnt += !pB2[j].is_inf();
+    wr32(o, cnt);
+    for (uint32_t j = 0; j < W; j++) if (!pB2[j].is_inf()) wr32(o, j);
+    for (uint32_t j = 0; j < W; j++) if (!pB2[j].is_inf()) wr_g2(o, pB2[j]);
+  }
+  sec1(pK, [&](uint32_t j) { return cls[j] == 0 && !pK[j].is_inf(); });
+  wr32(o, n - 1);
+  for (uint32_t i = 0; i + 1 < n; i++) wr_g1(o, pZ[i]);
+  wr32(o, (uint32_t)circ.committed.size());
+  for (uint32_t w : circ.committed) wr32(o, w);
+  for (uint32_t w : circ.committed) wr_g1(o, pK[w]);
+  wr32(o, (uint32_t)circ.committed.size());
+  for (uint32_t w : circ.committed) wr32(o, w);
+  for (uint32_t w : circ.committed) wr_g1(o, pS[w]);
+  if (!write_file(pk_path, o)) return fail(SPP_ERR_IO, "cannot write %s", pk_path);
+
+  std::vector<uint8_t> v;
+  wr_g1(v, pC[0]); wr_g1(v, pC[1]); wr_g2(v, pC2[0]); wr_g2(v, pC2[1]); wr_g1(v, pC[2]); wr_g2(v, pC2[2]);
+  wr32be(v, circ.n_public + 1);
+  for (uint32_t j = 0; j < circ.n_public; j++) wr_g1(v, pK[j]);
+  wr_g1(v, pK[circ.challenge_wire]);
+  wr32be(v, 1); wr32be(v, 0); wr32be(v, 1);
+  wr_g2(v, pC2[3]); wr_g2(v, pC2[4]);
+  if (!write_file(vk_path, v)) return fail(SPP_ERR_IO, "cannot write %s", vk_path);
+  return SPP_OK;
+}
+
+// -----------------------------------------------------------------------------------------------------
+// micro-benchmark / unit entry points
+// -----------------------------------------------------------------------------------------------------
+extern "C" int spp_ntt_fr(spp_ctx* ctx, uint8_t* data, uint32_t logn, int inverse) {
+  if (!ctx || !data || logn == 0 || logn > 24) return fail(SPP_ERR_BAD_INPUT, "bad argument");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_TRY(hipSetDevice(ctx->device));
+  const uint32_t n = 1u << logn;
+  Fr w = fr_root_of_unity(logn);
+  if (inverse) w = w.inv();
+  std::vector<Fr> tw(n / 2 ? n / 2 : 1), host(n);
+  Fr a = Fr::one();
+  for (uint32_t k = 0; k < n / 2; k++) { tw[k] = a; a = a * w; }
+  for (uint32_t i = 0; i < n; i++) host[i] = Fr::from_bytes_be(data + 32 * (size_t)i);
+  Fr *d_tw, *d_x;
+  HIP_TRY(hipMalloc((void**)&d_tw, sizeof(Fr) * tw.size()));
+  HIP_TRY(hipMalloc((void**)&d_x, sizeof(Fr) * n));
+  HIP_TRY(hipMemcpy(d_tw, tw.data(), sizeof(Fr) * tw.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_x, host.data(), sizeof(Fr) * n, hipMemcpyHostToDevice));
+  launch_ntt(ctx->stream, d_x, logn, 1, d_tw, true, 1, 0);   // DIF: natural in, bit-reversed out
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(host.data(), d_x, sizeof(Fr) * n, hipMemcpyDeviceToHost));
+  hipFree(d_tw);
+  hipFree(d_x);
+  Fr ninv = inverse ? Fr::from_u64(n).inv() : Fr::one();
+  for (uint32_t pos = 0; pos < n; pos++) {
+    Fr v = host[pos];
+    if (inverse) v = v * ninv;
+    v.to_bytes_be(data + 32 * (size_t)bitrev(pos, logn));
+  }
+  return SPP_OK;
+}
+
+extern "C" int spp_msm_g1(spp_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, int window_bits, uint8_t out[64]) {
+  if (!ctx || !out || (n && (!bases || !scalars))) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  if (window_bits == 0) window_bits = 8;
+  if (window_bits < 4 || window_bits > 16) return fail(SPP_ERR_BAD_INPUT, "window_bits outside [4,16]");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const uint32_t cb = (uint32_t)window_bits, Wn = msm_windows(cb), E = 1u << (cb - 1);
+  if ((uint64_t)n * Wn * E * 64 > ((uint64_t)64 << 30)) return fail(SPP_ERR_BAD_INPUT, "table would exceed 64 GiB; use a smaller window");
+  std::vector<G1Affine> pts(n);
+  std::vector<Fr> sc(n);
+  std::vector<uint32_t> rows(n);
+  for (size_t i = 0; i < n; i++) {
+    pts[i] = g1_from_raw(bases + 64 * i);
+    sc[i] = Fr::from_bytes_be(scalars + 32 * i);
+    rows[i] = (uint32_t)i;
+  }
+  spp_circuit tmpc;   // only used as an owner of device allocations
+  tmpc.ctx = ctx;
+  tmpc.c_bits = cb;
+  G1Affine* table = nullptr;
+  int e = build_table_chunked<Fq>(&tmpc, pts, cb, &table);
+  Fr* d_sc = nullptr;
+  uint32_t* d_rows = nullptr;
+  G1XYZZ *partial = nullptr, *d_out = nullptr;
+  uint32_t S = msm_slices((uint32_t)n, 1);
+  if (!e) e = own_upload(&tmpc, &d_sc, sc);
+  if (!e) e = own_upload(&tmpc, &d_rows, rows);
+  if (!e && hipMalloc((void**)&partial, sizeof(G1XYZZ) * S) != hipSuccess) e = fail(SPP_ERR_HIP, "hipMalloc");
+  if (!e && hipMalloc((void**)&d_out, sizeof(G1XYZZ)) != hipSuccess) e = fail(SPP_ERR_HIP, "hipMalloc");
+  G1XYZZ res = G1XYZZ::infinity();
+  if (!e) {
+    launch_msm_accumulate<Fq>(st, table, d_rows, d_sc, partial, (uint32_t)n, 1, cb, S);
+    launch_msm_reduce<Fq>(st, partial, d_out, 1, n ? S : 0);
+    if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) e = fail(SPP_ERR_HIP, "msm kernels failed");
+    else if (hipMemcpy(&res, d_out, sizeof res, hipMemcpyDeviceToHost) != hipSuccess) e = fail(SPP_ERR_HIP, "copy back failed");
+  }
+  for (void* p : tmpc.owned) hipFree(p);
+  if (partial) hipFree(partial);
+  if (d_out) hipFree(d_out);
+  if (e) return e;
+  g1_to_raw(res.to_affine(), out);
+  return SPP_OK;
+}

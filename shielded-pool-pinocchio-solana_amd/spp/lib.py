@@ -1,0 +1,70 @@
+"""ctypes binding of libspp.so -- fails loudly when the HIP library is missing."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libspp.so")
+_LIB = None
+
+SPP_OK = 0
+SPP_ERR_UNSAT = -4
+SPP_CIRCUIT_WITHDRAW = 1
+SPP_CIRCUIT_AUDIT = 2
+PROOF_LEN = 388
+
+
+class SppError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libspp error %d: %s" % (code, msg))
+        self.code = code
+
+
+class WithdrawInputs(ctypes.Structure):
+    _fields_ = [("root", ctypes.c_uint8 * 32), ("nullifier", ctypes.c_uint8 * 32), ("recipient", ctypes.c_uint8 * 32),
+                ("amount", ctypes.c_uint64), ("wa_commitment", ctypes.c_uint8 * 32), ("secret_key", ctypes.c_uint8 * 32),
+                ("owner_x", ctypes.c_uint8 * 32), ("owner_y", ctypes.c_uint8 * 32), ("randomness", ctypes.c_uint8 * 32),
+                ("index", ctypes.c_uint64), ("siblings", (ctypes.c_uint8 * 32) * 16)]
+
+
+def load_library():
+    """Returns the loaded libspp.so; raises if it has not been built (no fallback path exists)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libspp.so not found at %s -- build it with __graft_entry__.build() "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, cp, u32, sz, i32 = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_size_t, ctypes.c_int
+    L.spp_last_error.restype = cp
+    L.spp_version.restype = cp
+    L.spp_circuit_build.argtypes = [i32, vp, cp, ctypes.POINTER(u32)]
+    L.spp_init.argtypes = [i32, ctypes.POINTER(vp)]
+    L.spp_free_ctx.argtypes = [vp]
+    L.spp_free_ctx.restype = None
+    L.spp_setup.argtypes = [vp, cp, cp, cp, cp]
+    L.spp_load_circuit.argtypes = [vp, cp, cp, i32, ctypes.POINTER(vp)]
+    L.spp_free_circuit.argtypes = [vp]
+    L.spp_free_circuit.restype = None
+    L.spp_circuit_info.argtypes = [vp, ctypes.POINTER(u32)]
+    L.spp_circuit_table_bytes.argtypes = [vp]
+    L.spp_circuit_table_bytes.restype = ctypes.c_uint64
+    L.spp_prove_batch.argtypes = [vp, sz, cp, cp, vp, vp, vp]
+    L.spp_prove_batch_device.argtypes = [vp, sz, vp, vp, vp, vp, vp]
+    L.spp_sync.argtypes = [vp]
+    L.spp_last_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    L.spp_prove_withdraw.argtypes = [vp, ctypes.POINTER(WithdrawInputs), cp, vp, vp]
+    L.spp_debug_witness.argtypes = [vp, vp, sz]
+    L.spp_ntt_fr.argtypes = [vp, vp, u32, i32]
+    L.spp_msm_g1.argtypes = [vp, cp, cp, sz, i32, vp]
+    _LIB = L
+    return L
+
+
+def last_error():
+    return load_library().spp_last_error().decode()
+
+
+def check(rc):
+    if rc != 0:
+        raise SppError(rc, last_error())

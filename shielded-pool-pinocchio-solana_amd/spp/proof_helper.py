@@ -1,0 +1,116 @@
+"""Python mirror of the reference's client/proof.helper.ts (same names, argument meaning, side effects).
+
+    ShieldedPoolInputs   proof.helper.ts:6-21
+    CircuitConfig        proof.helper.ts:23-26
+    generateProof()      proof.helper.ts:28-72   (alias generate_proof)
+
+The reference writes <circuitDir>/Prover.toml (:29-52), spawns `nargo execute` (:55) and `sunspot prove`
+(:64) and reads target/<name>.proof and .pw back (:68-69).  Here the two child processes are replaced by
+one call into libspp (HIP); Prover.toml and the two output files are still written so that
+client/generate-proof-hex.ts-style consumers keep working.  Errors surface as exceptions, as execSync's do.
+"""
+import os
+from dataclasses import dataclass, field
+from typing import List, Union
+
+from .lib import SppError, SPP_CIRCUIT_WITHDRAW
+
+
+@dataclass
+class ShieldedPoolInputs:
+    # public inputs
+    root: str
+    nullifier: str
+    recipient: str
+    amount: Union[int, str]
+    wa_commitment: str
+    # private inputs
+    secret_key: str
+    owner_x: str
+    owner_y: str
+    randomness: str
+    index: Union[int, str]
+    siblings: List[str] = field(default_factory=list)
+
+
+@dataclass
+class CircuitConfig:
+    circuitDir: str
+    circuitName: str
+
+
+def prover_toml(inputs: ShieldedPoolInputs) -> str:
+    """Exact text of proof.helper.ts:32-50."""
+    toml = ""
+    toml += 'root = "%s"\n' % inputs.root
+    toml += 'nullifier = "%s"\n' % inputs.nullifier
+    toml += 'recipient = "%s"\n' % inputs.recipient
+    toml += "amount = %s\n" % inputs.amount
+    toml += 'wa_commitment = "%s"\n' % inputs.wa_commitment
+    toml += 'secret_key = "%s"\n' % inputs.secret_key
+    toml += 'owner_x = "%s"\n' % inputs.owner_x
+    toml += 'owner_y = "%s"\n' % inputs.owner_y
+    toml += 'randomness = "%s"\n' % inputs.randomness
+    toml += "index = %s\n" % inputs.index
+    toml += "siblings = [\n"
+    for sib in inputs.siblings:
+        toml += '  "%s",\n' % sib
+    toml += "]\n"
+    return toml
+
+
+def _field(v):
+    if isinstance(v, str):
+        return int(v, 16) if v.lower().startswith("0x") else int(v)
+    return int(v)
+
+
+def input_vector(inputs: ShieldedPoolInputs):
+    """Order of the circuit's input wires: 5 public then 21 private (proof.helper.ts:34-50)."""
+    if len(inputs.siblings) != 16:
+        raise ValueError("siblings must hold 16 elements (TREE_DEPTH, noir_circuit/src/main.nr:5)")
+    vals = [_field(getattr(inputs, k)) for k in ("root", "nullifier", "recipient", "amount", "wa_commitment",
+                                                 "secret_key", "owner_x", "owner_y", "randomness", "index")]
+    return vals + [_field(s) for s in inputs.siblings]
+
+
+_HANDLES = {}
+
+
+def _handle(config: CircuitConfig, window_bits=0):
+    """Circuit + proving key resident in HBM, loaded once per (dir, name) -- the reference re-reads
+    .ccs/.pk from disk in every `sunspot prove`."""
+    from .prover import Context
+    key = (os.path.abspath(config.circuitDir), config.circuitName)
+    if key not in _HANDLES:
+        target = os.path.join(config.circuitDir, "target")
+        ccs = os.path.join(target, config.circuitName + ".sppc")
+        pk = os.path.join(target, config.circuitName + ".pk")
+        for p in (ccs, pk):
+            if not os.path.exists(p):
+                raise FileNotFoundError("ENOENT: no such file or directory, open '%s' (run setup first)" % p)
+        ctx = Context(int(os.environ.get("SPP_DEVICE", "0")))
+        _HANDLES[key] = ctx.load_circuit(ccs, pk, window_bits)
+    return _HANDLES[key]
+
+
+def generateProof(config: CircuitConfig, inputs: ShieldedPoolInputs, rs=None):
+    """Synchronous; returns {"proof": bytes(388), "publicWitness": bytes(172)} like proof.helper.ts:71.
+    rs: optional (r, s) blinding for reproducible proofs (SPP_SEED-style parity runs)."""
+    with open(os.path.join(config.circuitDir, "Prover.toml"), "w") as f:
+        f.write(prover_toml(inputs))
+    h = _handle(config)
+    if h.circuit_id != SPP_CIRCUIT_WITHDRAW:
+        raise ValueError("generateProof expects the withdraw circuit")
+    proofs, pws, status = h.prove_batch([input_vector(inputs)], None if rs is None else [rs])
+    if status[0] != 0:
+        raise SppError(status[0], "inputs do not satisfy the circuit (Command failed: sunspot prove)")
+    target = os.path.join(config.circuitDir, "target")
+    with open(os.path.join(target, config.circuitName + ".proof"), "wb") as f:
+        f.write(proofs[0])
+    with open(os.path.join(target, config.circuitName + ".pw"), "wb") as f:
+        f.write(pws[0])
+    return {"proof": proofs[0], "publicWitness": pws[0]}
+
+
+generate_proof = generateProof

@@ -1,0 +1,109 @@
+"""Thin object layer over the C ABI: Context (one GPU), CircuitHandle (R1CS + pk + tables in HBM)."""
+import ctypes
+from .lib import load_library, check, SppError, PROOF_LEN, SPP_ERR_UNSAT
+
+
+def build_circuit(circuit_id, out_path, aux=None):
+    """`sunspot compile` equivalent (host only): writes the SPPC container, returns nbConstraints."""
+    L = load_library()
+    n = ctypes.c_uint32(0)
+    auxbuf = None
+    if aux is not None:
+        auxbuf = (ctypes.c_uint32 * len(aux))(*[int(v) for v in aux])
+    check(L.spp_circuit_build(int(circuit_id), auxbuf, out_path.encode(), ctypes.byref(n)))
+    return n.value
+
+
+class Context:
+    def __init__(self, device=0):
+        self.L = load_library()
+        h = ctypes.c_void_p()
+        check(self.L.spp_init(int(device), ctypes.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.L.spp_free_ctx(self.h)
+            self.h = None
+
+    def setup(self, circuit_path, seed32, pk_path, vk_path):
+        assert len(seed32) == 32
+        check(self.L.spp_setup(self.h, circuit_path.encode(), bytes(seed32), pk_path.encode(), vk_path.encode()))
+
+    def load_circuit(self, circuit_path, pk_path, window_bits=0):
+        return CircuitHandle(self, circuit_path, pk_path, window_bits)
+
+    def ntt(self, values, inverse=False):
+        """values: list of ints (len 2^k) -> list of ints, natural order."""
+        n = len(values)
+        logn = n.bit_length() - 1
+        assert 1 << logn == n
+        buf = ctypes.create_string_buffer(b"".join(int(v).to_bytes(32, "big") for v in values), 32 * n)
+        check(self.L.spp_ntt_fr(self.h, ctypes.cast(buf, ctypes.c_void_p), logn, 1 if inverse else 0))
+        return [int.from_bytes(buf.raw[32 * i:32 * i + 32], "big") for i in range(n)]
+
+    def msm_g1(self, bases_bytes, scalars, window_bits=8):
+        n = len(scalars)
+        out = ctypes.create_string_buffer(64)
+        sc = b"".join(int(s).to_bytes(32, "big") for s in scalars)
+        check(self.L.spp_msm_g1(self.h, bases_bytes, sc, n, int(window_bits), ctypes.cast(out, ctypes.c_void_p)))
+        return out.raw
+
+
+class CircuitHandle:
+    def __init__(self, ctx, circuit_path, pk_path, window_bits=0):
+        self.ctx = ctx
+        self.L = ctx.L
+        h = ctypes.c_void_p()
+        check(self.L.spp_load_circuit(ctx.h, circuit_path.encode(), pk_path.encode(), int(window_bits), ctypes.byref(h)))
+        self.h = h
+        info = (ctypes.c_uint32 * 8)()
+        check(self.L.spp_circuit_info(self.h, info))
+        (self.circuit_id, self.n_public, self.n_secret, self.n_wires, self.n_constraints, self.domain_log,
+         self.n_inputs, self.window_bits) = list(info)
+        self.pw_len = 12 + 32 * self.n_public
+
+    def close(self):
+        if self.h:
+            self.L.spp_free_circuit(self.h)
+            self.h = None
+
+    @property
+    def table_bytes(self):
+        return int(self.L.spp_circuit_table_bytes(self.h))
+
+    def prove_batch(self, inputs, rs=None):
+        """inputs: list (per proof) of lists of ints; rs: list of (r, s) ints or None (OS randomness).
+        Returns (proofs, pws, status) with status[i] == 0 or SPP_ERR_UNSAT."""
+        count = len(inputs)
+        buf = b"".join(int(v).to_bytes(32, "big") for row in inputs for v in row)
+        assert len(buf) == count * self.n_inputs * 32
+        rsb = None
+        if rs is not None:
+            rsb = b"".join(int(r).to_bytes(32, "big") + int(s).to_bytes(32, "big") for r, s in rs)
+        proofs = ctypes.create_string_buffer(PROOF_LEN * count)
+        pws = ctypes.create_string_buffer(self.pw_len * count)
+        status = (ctypes.c_int32 * count)()
+        rc = self.L.spp_prove_batch(self.h, count, buf, rsb, ctypes.cast(proofs, ctypes.c_void_p),
+                                    ctypes.cast(pws, ctypes.c_void_p), ctypes.cast(status, ctypes.c_void_p))
+        if rc != 0 and rc != SPP_ERR_UNSAT:
+            check(rc)
+        return ([proofs.raw[PROOF_LEN * i:PROOF_LEN * (i + 1)] for i in range(count)],
+                [pws.raw[self.pw_len * i:self.pw_len * (i + 1)] for i in range(count)], list(status))
+
+    def prove_batch_device(self, count, d_inputs, d_rs, d_proofs, d_pws, d_status):
+        """All arguments are raw device pointers (ints), e.g. torch tensors' data_ptr()."""
+        check(self.L.spp_prove_batch_device(self.h, count, d_inputs, d_rs, d_proofs, d_pws, d_status))
+
+    def sync(self):
+        check(self.L.spp_sync(self.h))
+
+    def last_timings(self):
+        ms = (ctypes.c_float * 9)()
+        check(self.L.spp_last_timings(self.h, ms))
+        return list(ms)
+
+    def debug_witness(self):
+        buf = ctypes.create_string_buffer(32 * self.n_wires)
+        check(self.L.spp_debug_witness(self.h, ctypes.cast(buf, ctypes.c_void_p), self.n_wires))
+        return [int.from_bytes(buf.raw[32 * i:32 * i + 32], "big") for i in range(self.n_wires)]

@@ -1,0 +1,158 @@
+"""GPU parity tests: the HIP path (through the C ABI, libspp.so) against the CPU oracle on the same inputs.
+Bit-exact comparison everywhere (integer / byte work)."""
+import os
+import random
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import spp
+    c = spp.Context(0)
+    yield c
+    c.close()
+
+
+def test_ntt_matches_oracle(ctx):
+    from oracle import native
+    import ctypes
+    rng = random.Random(5)
+    from oracle.bn254 import R
+    for logn in (1, 4, 8, 9, 13):
+        n = 1 << logn
+        vals = [rng.randrange(R) for _ in range(n)]
+        for inverse in (False, True):
+            got = ctx.ntt(vals, inverse)
+            buf = ctypes.create_string_buffer(b"".join(v.to_bytes(32, "big") for v in vals), 32 * n)
+            native.lib().orc_ntt(ctypes.cast(buf, ctypes.c_void_p), logn, 1 if inverse else 0)
+            exp = [int.from_bytes(buf.raw[32 * i:32 * i + 32], "big") for i in range(n)]
+            assert got == exp, (logn, inverse)
+    # round trip at the audit size
+    vals = [rng.randrange(R) for _ in range(1 << 15)]
+    assert ctx.ntt(ctx.ntt(vals, False), True) == vals
+
+
+def test_msm_g1_matches_oracle(ctx):
+    from oracle import bn254 as B, native
+    import ctypes
+    rng = random.Random(9)
+    pts = []
+    p = B.G1_GEN
+    for i in range(150):
+        p = B.g1_add(p, B.g1_mul(B.G1_GEN, rng.randrange(1, 1 << 64)))
+        pts.append(p)
+    bases = b"".join(B.g1_to_bytes(q) for q in pts)
+    for n, wb in ((0, 6), (1, 6), (7, 4), (150, 6), (150, 8)):
+        sc = [rng.randrange(B.R) for _ in range(n)]
+        if n >= 7:
+            sc[0] = 0
+            sc[1] = 1
+            sc[2] = B.R - 1          # -1: sign folding
+            sc[3] = (B.R - 1) // 2   # largest positive magnitude
+            sc[4] = (B.R + 1) // 2
+            sc[5] = 255
+        got = ctx.msm_g1(bases[:64 * n], sc, wb)
+        out = ctypes.create_string_buffer(64)
+        native.lib().orc_msm_g1(bases[:64 * n], b"".join(s.to_bytes(32, "big") for s in sc), n, ctypes.cast(out, ctypes.c_void_p))
+        assert got == out.raw, (n, wb)
+
+
+def test_setup_matches_oracle(ctx, withdraw_artifacts, workdir):
+    pk2 = os.path.join(workdir, "gpu.pk")
+    vk2 = os.path.join(workdir, "gpu.vk")
+    ctx.setup(withdraw_artifacts["sppc"], b"\x07" * 32, pk2, vk2)
+    assert open(vk2, "rb").read() == open(withdraw_artifacts["vk"], "rb").read()
+    assert open(pk2, "rb").read() == open(withdraw_artifacts["pk"], "rb").read()
+    assert os.path.getsize(vk2) == 1296   # size of the reference's shielded_pool_verifier.vk
+
+
+@pytest.fixture(scope="module")
+def withdraw_handle(ctx, withdraw_artifacts):
+    h = ctx.load_circuit(withdraw_artifacts["sppc"], withdraw_artifacts["pk"], 6)
+    yield h
+    h.close()
+
+
+def _withdraw_variants(kat, count):
+    """count input vectors: the reference KAT first, then fresh notes inserted in a tree (client/merkle.ts)."""
+    from oracle import circuit as C, hashes as H
+    rng = random.Random(77)
+    rows = [C.withdraw_inputs(kat)]
+    tree = H.MerkleTree()
+    notes = []
+    for i in range(count - 1):
+        sk = rng.randrange(1, 1 << 128)
+        owner = H.fixed_base_scalar_mul(sk)
+        amount = rng.randrange(1, 1 << 40)
+        rnd = rng.randrange(1 << 250)
+        cm = H.poseidon_hash4(owner[0], owner[1], amount, rnd)
+        idx = tree.insert(cm)
+        notes.append((sk, owner, amount, rnd, idx))
+    root = tree.root()
+    for sk, owner, amount, rnd, idx in notes:
+        rows.append([root, H.poseidon_hash2(sk, idx), rng.randrange(1, 1 << 240), amount, H.poseidon_hash2(owner[0], owner[1]),
+                     sk, owner[0], owner[1], rnd, idx] + tree.proof(idx))
+    return rows
+
+
+def test_withdraw_proof_bytes_match_oracle_and_verify(withdraw_handle, withdraw_artifacts, withdraw_kat):
+    from oracle import native, groth16
+    rows = _withdraw_variants(withdraw_kat, 5)
+    rs = [(1000 + i, 2000 + 7 * i) for i in range(len(rows))]
+    proofs, pws, status = withdraw_handle.prove_batch(rows, rs)
+    assert status == [0] * len(rows)
+    orc = native.Prover(withdraw_artifacts["sppc"], withdraw_artifacts["pk"])
+    vk = open(withdraw_artifacts["vk"], "rb").read()
+    for i, row in enumerate(rows):
+        rc, proof, pw = orc.prove(row, rs[i][0], rs[i][1])
+        assert rc == 0
+        assert pws[i] == pw == groth16.public_witness_bytes(row[:5])
+        assert proofs[i] == proof, "proof %d differs from the oracle" % i
+    assert groth16.verify(vk, proofs[0], pws[0])
+    assert groth16.verify(vk, proofs[3], pws[3])
+    bad = bytearray(proofs[0])
+    bad[0] ^= 1                     # client/test-shielded-pool.ts:386-392 corrupts byte 0
+    assert not groth16.verify(vk, bytes(bad), pws[0])
+
+
+def test_withdraw_witness_matches_oracle(withdraw_handle, withdraw_artifacts, withdraw_kat):
+    from oracle import native, circuit as C
+    row = C.withdraw_inputs(withdraw_kat)
+    withdraw_handle.prove_batch([row], [(5, 6)])
+    got = withdraw_handle.debug_witness()
+    orc = native.Prover(withdraw_artifacts["sppc"], withdraw_artifacts["pk"])
+    rc, _, _, wires = orc.prove(row, 5, 6, want_wires=True)
+    assert rc == 0 and got == wires
+
+
+def test_unsatisfied_inputs_are_refused(withdraw_handle, withdraw_kat):
+    from oracle import circuit as C
+    good = C.withdraw_inputs(withdraw_kat)
+    wrong_root = list(good); wrong_root[0] += 1
+    zero_recipient = list(good); zero_recipient[2] = 0          # main.nr:81
+    big_amount = list(good); big_amount[3] = 1 << 64            # amount: pub u64, main.nr:43
+    proofs, pws, status = withdraw_handle.prove_batch([good, wrong_root, zero_recipient, big_amount], [(1, 2)] * 4)
+    assert status[0] == 0 and status[1] == -4 and status[2] == -4 and status[3] == -4
+    assert proofs[1] == b"\x00" * 388
+
+
+def test_odd_batch_sizes_and_default_window(ctx, withdraw_artifacts, withdraw_kat):
+    """P = 1, 3, 70 (not multiples of the wavefront) and the default 10-bit window tables."""
+    from oracle import native
+    h = ctx.load_circuit(withdraw_artifacts["sppc"], withdraw_artifacts["pk"], 0)
+    try:
+        assert h.window_bits == 10
+        orc = native.Prover(withdraw_artifacts["sppc"], withdraw_artifacts["pk"])
+        rows = _withdraw_variants(withdraw_kat, 4)
+        for count in (1, 3, 70):
+            batch = [rows[i % len(rows)] for i in range(count)]
+            rs = [(i + 1, 3 * i + 2) for i in range(count)]
+            proofs, pws, status = h.prove_batch(batch, rs)
+            assert status == [0] * count
+            for i in sorted({0, count // 2, count - 1}):
+                rc, proof, pw = orc.prove(batch[i], rs[i][0], rs[i][1])
+                assert proofs[i] == proof and pws[i] == pw, (count, i)
+    finally:
+        h.close()
