@@ -81,6 +81,8 @@ int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const char* pk_path
 void spp_free_circuit(spp_circuit* c);
 /* info[0..7] = id, n_public (without the constant), n_secret, n_wires, n_constraints, domain_log, n_inputs, window_bits */
 int spp_circuit_info(const spp_circuit* c, uint32_t info[8]);
+/* number of bases per MSM of one proof: G1 sets A, B1, K, Z, commitment basis, commitment basis^sigma; then the G2 set B2 */
+int spp_circuit_msm_sizes(const spp_circuit* c, uint32_t sizes[7]);
 /* exact bytes of HBM held by the window tables */
 uint64_t spp_circuit_table_bytes(const spp_circuit* c);
 

@@ -552,6 +552,11 @@ extern "C" int spp_circuit_info(const spp_circuit* c, uint32_t info[8]) {
   return SPP_OK;
 }
 extern "C" uint64_t spp_circuit_table_bytes(const spp_circuit* c) { return c ? c->table_bytes : 0; }
+extern "C" int spp_circuit_msm_sizes(const spp_circuit* c, uint32_t sizes[7]) {
+  if (!c || !sizes) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  sizes[0] = c->A.N; sizes[1] = c->B1.N; sizes[2] = c->K.N; sizes[3] = c->Z.N; sizes[4] = c->CB.N; sizes[5] = c->CS.N; sizes[6] = c->B2.N;
+  return SPP_OK;
+}
 
 template <class T>
 static int ws_alloc(spp_circuit* c, T** p, size_t count) {

@@ -68,6 +68,11 @@ class CircuitHandle:
             self.L.spp_free_circuit(self.h)
             self.h = None
 
+    def msm_sizes(self):
+        s = (ctypes.c_uint32 * 7)()
+        check(self.L.spp_circuit_msm_sizes(self.h, s))
+        return list(s)
+
     @property
     def table_bytes(self):
         return int(self.L.spp_circuit_table_bytes(self.h))
