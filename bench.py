@@ -131,13 +131,17 @@ def main():
     rs_bytes = b"".join((1000003 * (rank * B + i) + 17).to_bytes(32, "big") + (998244353 * (rank * B + i) + 29).to_bytes(32, "big")
                         for i in range(B))
     rs = torch.frombuffer(bytearray(rs_bytes), dtype=torch.uint8).to(dev)
-    proofs = torch.zeros(B * 388, dtype=torch.uint8, device=dev)
-    pws = torch.zeros(B * h.pw_len, dtype=torch.uint8, device=dev)
-    status = torch.zeros(B, dtype=torch.int32, device=dev)
+    # two output sets: consecutive batches are pipelined on two streams inside libspp
+    proofs = [torch.zeros(B * 388, dtype=torch.uint8, device=dev) for _ in range(2)]
+    pws = [torch.zeros(B * h.pw_len, dtype=torch.uint8, device=dev) for _ in range(2)]
+    status = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)]
     torch.cuda.synchronize()
+    step_no = [0]
 
     def step():
-        h.prove_batch_device(B, inp.data_ptr(), rs.data_ptr(), proofs.data_ptr(), pws.data_ptr(), status.data_ptr())
+        k = step_no[0] & 1
+        step_no[0] += 1
+        h.prove_batch_device(B, inp.data_ptr(), rs.data_ptr(), proofs[k].data_ptr(), pws[k].data_ptr(), status[k].data_ptr())
 
     for _ in range(args.warmup):
         step()
@@ -148,14 +152,17 @@ def main():
     t0 = time.perf_counter()
     kern_ms, kern_n = 0.0, 0
     stage = [0.0] * 7
-    for _ in range(args.steps):
-        step()
-        # HIP-event timings are read after the step's own stream work (events live on the proving stream)
-        tm = h.last_timings()
+    def take(tm):
+        nonlocal kern_ms, kern_n
         kern_ms += tm[7] * tm[8]
         kern_n += int(tm[8])
         for i in range(7):
             stage[i] += tm[i]
+
+    for it in range(args.steps):
+        step()
+        if it >= 1:
+            take(h.last_timings(1))   # HIP events of the previous step; the step just enqueued keeps the GPU busy
     h.sync()
     torch.cuda.synchronize()
     if dist is not None:
@@ -165,7 +172,8 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert int(status.abs().sum().item()) == 0, "some synthetic proofs were refused as unsatisfied"
+    assert int(status[0].abs().sum().item()) + int(status[1].abs().sum().item()) == 0, "some synthetic proofs were refused"
+    take(h.last_timings(0))           # events of the last timed step (already complete)
 
     if rank == 0:
         total_proofs = B * world * args.steps
@@ -183,7 +191,7 @@ def main():
             "config": {"workload": "%s circuit, batch of %d independent proofs per GPU per step" % (
                 "noir_circuit withdraw (Poseidon Merkle depth 16 + Grumpkin)" if args.circuit == "withdraw" else "audit_circuit (RLWE)", B),
                 "circuit": args.circuit, "n_constraints": h.n_constraints, "n_wires": h.n_wires, "domain": 1 << h.domain_log,
-                "batch_per_gpu": B, "window_bits": h.window_bits, "table_bytes": h.table_bytes, "parallelism": "independent proofs x%d" % world,
+                "batch_per_gpu": B, "window_bits": h.window_bits, "msm_sizes": dict(zip(["A", "B1", "K", "Z", "CB", "CS", "B2(G2)"], sizes)), "table_bytes": h.table_bytes, "parallelism": "independent proofs x%d" % world,
                 "pk_bcast_ms": round(bcast_ms, 3), "setup_s": round(setup_s, 2), "load_s": round(load_s, 2)},
             "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in zip(
                 ["solve+commit", "matrix_eval", "ntt_qap", "msm_g1", "msm_g2", "assemble", "total"], stage)},
@@ -195,16 +203,18 @@ def main():
         if not args.no_cpu_baseline:
             orc = native.Prover(sppc, pkp)
             cores = native.max_threads()
+            # throughput mode: one proof per host thread, rounds of `cores` proofs until ~12 s have elapsed
             t1 = time.perf_counter()
             done = 0
-            while done < 3 or (time.perf_counter() - t1 < 12.0 and done < 400):
-                rc, _, _ = orc.prove(rows[done % len(rows)], 7 + done, 11 + done)
+            while done == 0 or (time.perf_counter() - t1 < 12.0 and done < 4096):
+                batch = [rows[(done + i) % len(rows)] for i in range(cores)]
+                rc, _, _ = native.prove_many(orc, batch, [(7 + done + i, 11 + done + i) for i in range(cores)])
                 assert rc == 0
-                done += 1
+                done += cores
             dt = time.perf_counter() - t1
             out["cpu_baseline"] = {"value": round(done / dt, 3), "unit": "proofs/s", "cores": cores, "kind": "port",
-                                   "sample": "%d %s proofs, oracle C/OpenMP prover (stands in for the Sunspot Go/CPU path, "
-                                             "which cannot run here: no Go toolchain, no pk)" % (done, args.circuit)}
+                                   "sample": "%d %s proofs, one per host thread, oracle C/OpenMP prover (stands in for the Sunspot "
+                                             "Go/CPU path, which cannot run here: no Go toolchain, no pk)" % (done, args.circuit)}
         print(json.dumps(out), flush=True)
     h.close()
     ctx.close()

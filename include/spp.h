@@ -92,8 +92,10 @@ uint64_t spp_circuit_table_bytes(const spp_circuit* c);
  * status[count] (0 ok, SPP_ERR_UNSAT). Returns 0 if every proof was produced, else the first error. */
 int spp_prove_batch(spp_circuit* c, size_t count, const uint8_t* inputs, const uint8_t* rs, uint8_t* proofs, uint8_t* pws,
                     int32_t* status);
-/* Same with every buffer already resident in HBM (device pointers); asynchronous on the circuit's stream
- * until spp_sync(). d_status: uint32 per proof, nonzero = unsatisfied. */
+/* Same with every buffer already resident in HBM (device pointers); asynchronous until spp_sync().
+ * Consecutive calls alternate between two HIP streams and two workspaces, so the latency-bound witness solver of
+ * batch k+1 overlaps the MSMs of batch k: output buffers must not be shared by two consecutive calls.
+ * d_status: uint32 per proof, nonzero = unsatisfied. */
 int spp_prove_batch_device(spp_circuit* c, size_t count, const void* d_inputs, const void* d_rs, void* d_proofs, void* d_pws,
                            void* d_status);
 int spp_sync(spp_circuit* c);
@@ -101,6 +103,9 @@ int spp_sync(spp_circuit* c);
  * [0] witness solve (+commitment), [1] matrix eval, [2] NTT/QAP, [3] MSM G1, [4] MSM G2, [5] assembly, [6] total;
  * [7] = average duration of one k_msm_fixed<G1> launch (the dominant kernel), [8] = number of such launches */
 int spp_last_timings(spp_circuit* c, float ms[9]);
+/* which = 0: the last enqueued batch, 1: the one before it (consecutive batches alternate between two streams,
+ * so reading batch k-1 while batch k runs does not drain the pipeline) */
+int spp_timings(spp_circuit* c, int which, float ms[9]);
 
 int spp_prove_withdraw(spp_circuit* c, const spp_withdraw_inputs* in, const uint8_t rs_seed[64], uint8_t proof[SPP_PROOF_LEN],
                        uint8_t pw[SPP_WITHDRAW_PW_LEN]);

@@ -21,12 +21,13 @@
 /* ------------------------------------------------------------------------------------------------ */
 /* circuit container                                                                                 */
 /* ------------------------------------------------------------------------------------------------ */
-enum { OP_END, OP_SOLVE_C, OP_SOLVE_A, OP_BATCH_DIV, OP_BITS, OP_LIMBS8, OP_COUNT8, OP_POSEIDON, OP_POSEIDON2, OP_COMMIT };
+enum { OP_END, OP_SOLVE_C, OP_SOLVE_A, OP_BATCH_DIV, OP_BITS, OP_LIMBS8, OP_COUNT8, OP_POSEIDON, OP_POSEIDON2, OP_COMMIT, OP_GRUMPKIN };
 
 typedef struct { uint32_t rows, nnz; uint32_t* rowptr; uint32_t* wire; uint32_t* coeff; } sparse_t;
 typedef struct {
-  uint32_t id, n_public, n_secret, n_wires, n_constraints, domain_log, challenge_wire, n_coeffs, n_committed, n_prog;
+  uint32_t id, n_public, n_secret, n_wires, n_constraints, domain_log, challenge_wire, n_coeffs, n_committed, n_prog, n_aux;
   fe* coeffs;
+  fe* aux;
   sparse_t A, B, C, H;
   uint32_t* committed;
   uint32_t* prog;
@@ -66,11 +67,11 @@ static circuit_t* circuit_load(const char* path) {
   uint8_t* buf = read_file(path, &len);
   if (!buf) return NULL;
   const uint8_t* p = buf;
-  if (rd32(&p) != 0x43505053u || rd32(&p) != 1) { free(buf); return NULL; }
+  if (rd32(&p) != 0x43505053u || rd32(&p) != 2) { free(buf); return NULL; }
   circuit_t* c = (circuit_t*)calloc(1, sizeof *c);
   c->id = rd32(&p); c->n_public = rd32(&p); c->n_secret = rd32(&p); c->n_wires = rd32(&p);
   c->n_constraints = rd32(&p); c->domain_log = rd32(&p); c->challenge_wire = rd32(&p);
-  c->n_coeffs = rd32(&p); c->n_committed = rd32(&p); c->n_prog = rd32(&p);
+  c->n_coeffs = rd32(&p); c->n_committed = rd32(&p); c->n_prog = rd32(&p); c->n_aux = rd32(&p);
   c->coeffs = (fe*)malloc(sizeof(fe) * c->n_coeffs);
   for (uint32_t i = 0; i < c->n_coeffs; i++) {
     uint64_t v[4];
@@ -82,6 +83,12 @@ static circuit_t* circuit_load(const char* path) {
   for (uint32_t i = 0; i < c->n_committed; i++) c->committed[i] = rd32(&p);
   c->prog = (uint32_t*)malloc(4 * (size_t)c->n_prog + 4);
   for (uint32_t i = 0; i < c->n_prog; i++) c->prog[i] = rd32(&p);
+  c->aux = (fe*)malloc(sizeof(fe) * (size_t)c->n_aux + 1);
+  for (uint32_t i = 0; i < c->n_aux; i++) {
+    uint64_t v[4];
+    for (int j = 0; j < 4; j++) { uint64_t lo = rd32(&p); uint64_t hi = rd32(&p); v[j] = lo | (hi << 32); }
+    fe_from_raw(&c->aux[i], v, &FR);
+  }
   free(buf);
   return c;
 }
@@ -371,6 +378,38 @@ static int solve(const circuit_t* c, fe* w, challenge_fn chal, void* chal_ctx) {
         fe s[4];
         for (uint32_t i = 0; i < 4; i++) row_dot(&s[i], c, &c->H, h0 + i, w);
         poseidon2_permute(s, &w[out0]);
+        break;
+      }
+      case OP_GRUMPKIN: {
+        /* slopes of the affine ladder over Grumpkin (y^2 = x^3 - 17 over Fr): acc_0 = O, acc += T_j[digit_j], then + N */
+        uint32_t bit0 = pr[pc + 1], nbits = pr[pc + 2], aux_off = pr[pc + 3], nl = pr[pc + 4];
+        const uint32_t* lw = &pr[pc + 5];
+        pc += 5 + nl;
+        const fe* aux = c->aux + aux_off;
+        fe ax = aux[0], ay = aux[1];
+        for (uint32_t j = 0; j < nl; j++) {
+          fe sx, sy;
+          if (j < 64) {
+            uint32_t d = 0;
+            for (uint32_t k = 0; k < 4; k++) {
+              uint32_t bi = 4 * j + k;
+              if (bi < nbits && !fe_is_zero(&w[bit0 + bi])) d |= 1u << k;
+            }
+            sx = aux[4 + (j * 16 + d) * 2];
+            sy = aux[4 + (j * 16 + d) * 2 + 1];
+          } else {
+            sx = aux[2];
+            sy = aux[3];
+          }
+          fe dx, dy, lam, t, x3, y3;
+          fe_sub(&dx, &sx, &ax, &FR);
+          fe_sub(&dy, &sy, &ay, &FR);
+          if (fe_is_zero(&dx)) { memset(&lam, 0, sizeof lam); } else { fe_inv(&t, &dx, &FR); fe_mul(&lam, &dy, &t, &FR); }
+          w[lw[j]] = lam;
+          fe_sqr(&x3, &lam, &FR); fe_sub(&x3, &x3, &ax, &FR); fe_sub(&x3, &x3, &sx, &FR);
+          fe_sub(&t, &ax, &x3, &FR); fe_mul(&y3, &lam, &t, &FR); fe_sub(&y3, &y3, &ay, &FR);
+          ax = x3; ay = y3;
+        }
         break;
       }
       case OP_COMMIT: {
@@ -1004,6 +1043,24 @@ int orc_prove(void* ctx, const uint8_t* inputs, const uint8_t r32[32], const uin
   }
   free(w); free(a); free(b); free(cv);
   return 0;
+}
+
+/* Throughput mode for the CPU baseline: `count` independent proofs, one per OpenMP thread (the inner
+ * parallel regions of orc_prove then run single-threaded: nested parallelism is off by default). */
+int orc_prove_many(void* ctx, int count, const uint8_t* inputs, const uint8_t* rs, uint8_t* proofs, uint8_t* pws) {
+  orc_ctx* x = (orc_ctx*)ctx;
+  uint32_t nin = x->c->n_public - 1 + x->c->n_secret, np = x->c->n_public - 1;
+  int bad = 0;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int i = 0; i < count; i++) {
+    int rc = orc_prove(ctx, inputs + (size_t)i * nin * 32, rs + (size_t)i * 64, rs + (size_t)i * 64 + 32, proofs + (size_t)i * 388,
+                       pws + (size_t)i * (12 + 32 * np), NULL);
+    if (rc) {
+#pragma omp atomic write
+      bad = rc;
+    }
+  }
+  return bad;
 }
 
 void orc_set_threads(int n) { omp_set_num_threads(n); }

@@ -11,7 +11,7 @@ import struct
 from .bn254 import R, inv
 from . import hashes
 
-OP_END, OP_SOLVE_C, OP_SOLVE_A, OP_BATCH_DIV, OP_BITS, OP_LIMBS8, OP_COUNT8, OP_POSEIDON, OP_POSEIDON2, OP_COMMIT = range(10)
+OP_END, OP_SOLVE_C, OP_SOLVE_A, OP_BATCH_DIV, OP_BITS, OP_LIMBS8, OP_COUNT8, OP_POSEIDON, OP_POSEIDON2, OP_COMMIT, OP_GRUMPKIN = range(11)
 
 
 class Sparse:
@@ -36,9 +36,9 @@ class Circuit:
             off[0] += 4 * n
             return v
         magic, version = u32s(2)
-        assert magic == 0x43505053 and version == 1
+        assert magic == 0x43505053 and version == 2
         (self.id, self.n_public, self.n_secret, self.n_wires, self.n_constraints, self.domain_log,
-         self.challenge_wire, ncoef, ncommitted, nprog) = u32s(10)
+         self.challenge_wire, ncoef, ncommitted, nprog, naux) = u32s(11)
         self.coeffs = []
         for _ in range(ncoef):
             limbs = u32s(8)
@@ -55,6 +55,10 @@ class Circuit:
         self.A, self.B, self.C, self.H = mats
         self.committed = list(u32s(ncommitted))
         self.program = list(u32s(nprog))
+        self.aux = []
+        for _ in range(naux):
+            limbs = u32s(8)
+            self.aux.append(sum(l << (32 * i) for i, l in enumerate(limbs)))
         assert off[0] == len(data)
         self.n = 1 << self.domain_log
 
@@ -185,6 +189,24 @@ def solve(circ, inputs, challenge_fn):
             h0, out0 = prog[pc + 1:pc + 3]
             pc += 3
             _poseidon2_native([_dot(circ.H, h0 + i, w) for i in range(4)], out0, w)
+        elif op == OP_GRUMPKIN:
+            # slopes of the fixed-base ladder acc <- acc + T_j[digit_j] (acc_0 = O), then + N
+            bit0, nbits, aux_off, nl = prog[pc + 1:pc + 5]
+            lam_wires = prog[pc + 5:pc + 5 + nl]
+            pc += 5 + nl
+            aux = circ.aux
+            acc = (aux[aux_off], aux[aux_off + 1])
+            bits = [w[bit0 + i] if i < nbits else 0 for i in range(256)]
+            pts = []
+            for j in range(64):
+                d = bits[4 * j] + 2 * bits[4 * j + 1] + 4 * bits[4 * j + 2] + 8 * bits[4 * j + 3]
+                o = aux_off + 4 + (j * 16 + d) * 2
+                pts.append((aux[o], aux[o + 1]))
+            pts.append((aux[aux_off + 2], aux[aux_off + 3]))
+            for j, s_pt in enumerate(pts):
+                den = (s_pt[0] - acc[0]) % R
+                w[lam_wires[j]] = (s_pt[1] - acc[1]) * inv(den, R) % R if den else 0
+                acc = hashes.grumpkin_add(acc, s_pt)
         elif op == OP_COMMIT:
             pc += 1
             w[circ.challenge_wire] = challenge_fn(w) % R

@@ -25,6 +25,7 @@ def lib():
         for f in ("orc_n_inputs", "orc_n_public", "orc_n_wires", "orc_n_constraints"):
             getattr(L, f).argtypes = [ctypes.c_void_p]
             getattr(L, f).restype = ctypes.c_uint32
+        L.orc_prove_many.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p]
         L.orc_msm_g1.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p]
         L.orc_ntt.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int]
         _LIB = L
@@ -62,6 +63,18 @@ class Prover:
             w = [int.from_bytes(wires.raw[32 * i:32 * i + 32], "big") for i in range(self.n_wires)]
             out += (w,)
         return out
+
+
+def prove_many(prover, rows, rs):
+    """One proof per OpenMP thread (throughput mode). Returns (rc, proofs, pws)."""
+    count = len(rows)
+    buf = b"".join(int(v).to_bytes(32, "big") for row in rows for v in row)
+    rsb = b"".join(int(r).to_bytes(32, "big") + int(s).to_bytes(32, "big") for r, s in rs)
+    proofs = ctypes.create_string_buffer(388 * count)
+    pwl = 12 + 32 * prover.n_public
+    pws = ctypes.create_string_buffer(pwl * count)
+    rc = lib().orc_prove_many(prover.h, count, buf, rsb, ctypes.cast(proofs, ctypes.c_void_p), ctypes.cast(pws, ctypes.c_void_p))
+    return rc, [proofs.raw[388 * i:388 * (i + 1)] for i in range(count)], [pws.raw[pwl * i:pwl * (i + 1)] for i in range(count)]
 
 
 def set_threads(n):

@@ -10,7 +10,7 @@ namespace spp {
 // SPPC file
 // =====================================================================================================
 static const uint32_t SPPC_MAGIC = 0x43505053u;  // "SPPC"
-static const uint32_t SPPC_VERSION = 1;
+static const uint32_t SPPC_VERSION = 2;
 
 static void put_u32(std::vector<uint8_t>& o, uint32_t v) {
   for (int i = 0; i < 4; i++) o.push_back((uint8_t)(v >> (8 * i)));
@@ -39,6 +39,7 @@ bool Circuit::save(const std::string& path) const {
   put_u32(o, (uint32_t)coeffs.size());
   put_u32(o, (uint32_t)committed.size());
   put_u32(o, (uint32_t)program.size());
+  put_u32(o, (uint32_t)aux.size());
   for (auto& c : coeffs) {
     uint32_t cl[8];
     c.to_canonical(cl);
@@ -50,6 +51,11 @@ bool Circuit::save(const std::string& path) const {
   put_sparse(o, H);
   for (uint32_t w : committed) put_u32(o, w);
   for (uint32_t w : program) put_u32(o, w);
+  for (auto& a : aux) {
+    uint32_t cl[8];
+    a.to_canonical(cl);
+    for (int i = 0; i < 8; i++) put_u32(o, cl[i]);
+  }
   FILE* f = fopen(path.c_str(), "wb");
   if (!f) return false;
   bool ok = fwrite(o.data(), 1, o.size(), f) == o.size();
@@ -105,7 +111,7 @@ bool Circuit::load(const std::string& path) {
   n_constraints = r.u32();
   domain_log = r.u32();
   challenge_wire = r.u32();
-  uint32_t nc = r.u32(), ncm = r.u32(), np = r.u32();
+  uint32_t nc = r.u32(), ncm = r.u32(), np = r.u32(), naux = r.u32();
   if (!r.ok || (size_t)nc * 32 > buf.size()) return false;
   coeffs.resize(nc);
   for (auto& c : coeffs) {
@@ -118,6 +124,13 @@ bool Circuit::load(const std::string& path) {
   for (auto& w : committed) w = r.u32();
   program.resize(np);
   for (auto& w : program) w = r.u32();
+  if ((size_t)naux * 32 > buf.size()) return false;
+  aux.resize(naux);
+  for (auto& a : aux) {
+    uint32_t cl[8];
+    for (int i = 0; i < 8; i++) cl[i] = r.u32();
+    a = Fr::from_canonical(cl);
+  }
   return r.ok;
 }
 
@@ -373,25 +386,44 @@ Fr fr_from_hex(const char* h) {
 GkAffine grumpkin_generator() { return {Fr::one(), fr_from_hex(GK_GEN_Y)}; }
 GkAffine grumpkin_offset() { return {fr_from_hex(GK_OFFSET_X), fr_from_hex(GK_OFFSET_Y)}; }
 
-static std::pair<LC, LC> affine_add_incomplete(Builder& b, const LC& x1, const LC& y1, const LC& x2, const LC& y2) {
+static std::pair<LC, LC> affine_add_incomplete(Builder& b, const LC& x1, const LC& y1, const LC& x2, const LC& y2, bool defer = false) {
   if (x1.is_constant() && y1.is_constant() && x2.is_constant() && y2.is_constant()) {
     GkXYZZ a = GkXYZZ::from_affine({x1.constant_value(), y1.constant_value()});
     a.madd({x2.constant_value(), y2.constant_value()});
     GkAffine r = a.to_affine();
     return {LC::constant(r.x), LC::constant(r.y)};
   }
-  LC lam = b.div(y2 - y1, x2 - x1);
+  LC lam = b.div(y2 - y1, x2 - x1, defer);
   LC x3 = b.mul_sub(lam, lam, x1 + x2);
   LC y3 = b.mul_sub(lam, x1 - x3, y1);
   return {x3, y3};
 }
 
-std::pair<LC, LC> gadget_grumpkin_fixed_base(Builder& b, const std::vector<LC>& bits_in) {
+std::pair<LC, LC> gadget_grumpkin_fixed_base(Builder& b, const std::vector<LC>& bits_in, bool native_hint) {
   std::vector<LC> bits = bits_in;
+  // native hint: all 65 slopes of the ladder are produced by OP_GRUMPKIN from the scalar bits (two shared
+  // inversions instead of 65); operands: first bit wire, #bits, aux offset, #slopes, slope wires (patched below)
+  size_t patch = 0;
+  uint32_t aux_off = (uint32_t)b.aux().size();
+  std::vector<uint32_t> lam_wires;
+  if (native_hint) {
+    auto& pr = b.program();
+    pr.push_back(OP_GRUMPKIN);
+    pr.push_back(bits_in[0].t[0].first);
+    pr.push_back((uint32_t)bits_in.size());
+    pr.push_back(aux_off);
+    pr.push_back(65);
+    patch = pr.size();
+    for (int i = 0; i < 65; i++) pr.push_back(0);
+    for (size_t i = 1; i < bits_in.size(); i++)
+      if (bits_in[i].t.size() != 1 || bits_in[i].t[0].first != bits_in[0].t[0].first + i) abort();  // consecutive bit wires
+    b.aux().resize(aux_off + 4 + 64 * 16 * 2);
+  }
   while (bits.size() < 256) bits.push_back(LC());
   GkAffine G = grumpkin_generator();
   GkAffine O = grumpkin_offset();
   LC ax = LC::constant(O.x), ay = LC::constant(O.y);
+  if (native_hint) { b.aux()[aux_off] = O.x; b.aux()[aux_off + 1] = O.y; }
   GkXYZZ base = GkXYZZ::from_affine(G);       // 16^j * G
   GkXYZZ corr = GkXYZZ::from_affine(O);       // O + sum_j 16^j G
   for (int j = 0; j < 64; j++) {
@@ -404,6 +436,11 @@ std::pair<LC, LC> gadget_grumpkin_fixed_base(Builder& b, const std::vector<LC>& 
       run.madd(base_aff);
     }
     corr.madd(base_aff);
+    if (native_hint)
+      for (int d = 0; d < 16; d++) {
+        b.aux()[aux_off + 4 + (j * 16 + d) * 2] = T[d].x;
+        b.aux()[aux_off + 4 + (j * 16 + d) * 2 + 1] = T[d].y;
+      }
     // base for the next window is 16*base = T[15]
     base = GkXYZZ::from_affine(T[15]);
     const LC& b0 = bits[4 * j + 0];
@@ -427,12 +464,20 @@ std::pair<LC, LC> gadget_grumpkin_fixed_base(Builder& b, const std::vector<LC>& 
       LC p3 = b.mul(b23, L[3] - L[2] - L[1] + L[0]);
       sel[coord] = L[0] + p1 + p2 + p3;
     }
-    auto r = affine_add_incomplete(b, ax, ay, sel[0], sel[1]);
+    auto r = affine_add_incomplete(b, ax, ay, sel[0], sel[1], native_hint);
+    lam_wires.push_back(b.last_div_wire());
     ax = r.first;
     ay = r.second;
   }
   GkAffine N = corr.to_affine().neg();
-  return affine_add_incomplete(b, ax, ay, LC::constant(N.x), LC::constant(N.y));
+  auto res = affine_add_incomplete(b, ax, ay, LC::constant(N.x), LC::constant(N.y), native_hint);
+  lam_wires.push_back(b.last_div_wire());
+  if (native_hint) {
+    b.aux()[aux_off + 2] = N.x;
+    b.aux()[aux_off + 3] = N.y;
+    for (int i = 0; i < 65; i++) b.program()[patch + i] = lam_wires[i];
+  }
+  return res;
 }
 
 // =====================================================================================================
@@ -462,7 +507,7 @@ Circuit build_withdraw_circuit(bool native_hints) {
   for (int i = 0; i < 8; i++) rm1[i] = FrParams::MOD(i);
   rm1[0] -= 1;
   b.assert_bits_leq_const(skbits, rm1);
-  auto pk = gadget_grumpkin_fixed_base(b, skbits);
+  auto pk = gadget_grumpkin_fixed_base(b, skbits, native_hints);
   b.assert_eq(pk.first, owner_x);
   b.assert_eq(pk.second, owner_y);
 

@@ -36,7 +36,7 @@ enum : uint32_t {
   OP_POSEIDON = 7,    // t h0 out0    : native Poseidon permutation of (<H_h0..>), writes x^2,x^4,x^5 per S-box
   OP_POSEIDON2 = 8,   // h0 out0      : native Poseidon2 t=4 permutation, same wire convention
   OP_COMMIT = 9,      //              : phase boundary: the challenge wire is filled in before continuing
-  OP_RLWE_ROWS = 10,  // reserved (audit circuit: negacyclic inner-product rows, checked by the RLWE kernel)
+  OP_GRUMPKIN = 10,   // bit0 nbits aux_off n  w_0..w_{n-1} : slopes of the fixed-base Grumpkin ladder (see circuit.cpp)
 };
 
 enum : uint32_t { CIRCUIT_WITHDRAW = 1, CIRCUIT_AUDIT = 2 };
@@ -64,6 +64,7 @@ struct Circuit {
   Sparse A, B, C, H;
   std::vector<uint32_t> committed;      // wires bound by the commitment (private)
   std::vector<uint32_t> program;
+  std::vector<Fr> aux;                  // constants read by native hints (Grumpkin window tables)
   uint32_t n_inputs() const { return n_public - 1 + n_secret; }
   bool save(const std::string& path) const;
   bool load(const std::string& path);
@@ -160,6 +161,7 @@ class Builder {
   // out = num/den  (constraint out*den = num). If `defer` the instruction is left to a later batch_div().
   LC div(const LC& num, const LC& den, bool defer = false) {
     uint32_t out = new_wire();
+    last_div_wire_ = out;
     uint32_t k = constrain(LC::wire(out), den, num);
     if (!defer) {
       c_.program.push_back(OP_SOLVE_A);
@@ -260,6 +262,9 @@ class Builder {
   Circuit finish();
 
   Circuit& raw() { return c_; }
+  uint32_t last_div_wire() const { return last_div_wire_; }
+  std::vector<uint32_t>& program() { return c_.program; }
+  std::vector<Fr>& aux() { return c_.aux; }
 
  private:
   uint32_t coeff_index(const Fr& c) {
@@ -286,6 +291,7 @@ class Builder {
   std::map<std::string, uint32_t> coeff_map_;
   std::vector<LC> lookups_;
   bool finalized_ = false;
+  uint32_t last_div_wire_ = 0;
 };
 
 // ---- gadgets (circuit_gadgets.cpp) -----------------------------------------------------------------
@@ -304,7 +310,7 @@ const Poseidon2Params& poseidon2_params();
 LC gadget_poseidon_hash(Builder& b, const std::vector<LC>& inputs, bool native_hint);   // t = inputs+1
 void gadget_poseidon2_permute(Builder& b, LC state[4], bool native_hint);
 // Grumpkin fixed-base multiplication by the 254 little-endian bits of the scalar; returns (x, y)
-std::pair<LC, LC> gadget_grumpkin_fixed_base(Builder& b, const std::vector<LC>& bits);
+std::pair<LC, LC> gadget_grumpkin_fixed_base(Builder& b, const std::vector<LC>& bits, bool native_hint);
 
 Circuit build_withdraw_circuit(bool native_hints);
 Circuit build_audit_circuit(const uint32_t* pk_a, const uint32_t* pk_b, bool native_hints);

@@ -25,6 +25,7 @@ static constexpr uint32_t COEFF_MASK = 0x3fffffffu;
 struct DevCircuit {
   DevSparse A, B, C, H;
   const Fr* coeffs;
+  const Fr* aux;            // hint constants (Grumpkin window tables)
   const uint32_t* program;
   uint32_t n_wires, n_constraints, n_public, n_inputs, challenge_wire;
   // hash constants (Montgomery)
@@ -36,7 +37,8 @@ struct DevCircuit {
 // ---- witness ----
 void launch_load_inputs(hipStream_t st, const uint8_t* d_inputs_be, const uint8_t* d_rs_be, Fr* W, uint32_t n_inputs,
                         uint32_t n_wires, uint32_t P);
-// runs the solver program from word `pc` until OP_COMMIT / OP_END; scratch: [max_batch_div][P] Fr
+// runs the solver program from word `pc` until OP_COMMIT / OP_END; scratch: [SOLVE_SCRATCH_ROWS or more][P] Fr
+static constexpr uint32_t SOLVE_SCRATCH_MIN_ROWS = 324;
 void launch_solve(hipStream_t st, DevCircuit dc, Fr* W, Fr* scratch, uint32_t pc, uint32_t P);
 // a,b,c evaluation + satisfaction check (status[p] |= 1 when some row fails)
 void launch_spmv_check(hipStream_t st, DevCircuit dc, const Fr* W, Fr* abc, uint32_t n, uint32_t P, uint32_t* status);

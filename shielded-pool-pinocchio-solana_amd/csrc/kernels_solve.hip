@@ -158,6 +158,66 @@ __device__ __noinline__ void dev_div_range(const DevCircuit& dc, Fr* __restrict_
   }
 }
 
+// OP_GRUMPKIN: slopes of the affine ladder acc <- acc + T_j[digit_j] (acc_0 = O), then + N, over Grumpkin.
+// The ladder is first walked in XYZZ coordinates (no inversions), every intermediate point is normalised
+// with ONE shared inversion, and the 65 slope denominators with a second one.
+__device__ __noinline__ void dev_grumpkin(const DevCircuit& dc, Fr* __restrict__ W, Fr* __restrict__ scratch, uint32_t bit0, uint32_t nbits,
+                                          uint32_t aux_off, uint32_t nl, const uint32_t* __restrict__ lw, uint32_t P, uint32_t p) {
+  const Fr* __restrict__ aux = dc.aux + aux_off;
+  auto digit = [&](uint32_t j) {
+    uint32_t d = 0;
+    for (uint32_t k = 0; k < 4; k++) {
+      const uint32_t bi = 4 * j + k;
+      if (bi < nbits && !W[(size_t)(bit0 + bi) * P + p].is_zero()) d |= 1u << k;
+    }
+    return d;
+  };
+  auto sel = [&](uint32_t j) -> GkAffine {
+    if (j >= 64) return {aux[2], aux[3]};
+    const uint32_t o = 4 + (j * 16 + digit(j)) * 2;
+    return {aux[o], aux[o + 1]};
+  };
+  auto row = [&](uint32_t r) -> Fr& { return scratch[(size_t)r * P + p]; };
+  const GkAffine O{aux[0], aux[1]};
+  GkXYZZ acc = GkXYZZ::from_affine(O);
+  Fr prod = Fr::one();
+  for (uint32_t j = 0; j < 64; j++) {
+    acc.madd(sel(j));
+    row(5 * j) = acc.X; row(5 * j + 1) = acc.Y; row(5 * j + 2) = acc.ZZ; row(5 * j + 3) = acc.ZZZ;
+    row(5 * j + 4) = prod;
+    prod = prod * (acc.ZZ * acc.ZZZ);
+  }
+  Fr inv = prod.inv();
+  for (uint32_t j = 64; j-- > 0;) {
+    Fr X = row(5 * j), Y = row(5 * j + 1), ZZ = row(5 * j + 2), ZZZ = row(5 * j + 3);
+    Fr I = inv * row(5 * j + 4);
+    inv = inv * (ZZ * ZZZ);
+    row(5 * j) = X * (I * ZZZ);      // affine x of acc_j
+    row(5 * j + 1) = Y * (I * ZZ);   // affine y of acc_j
+  }
+  prod = Fr::one();
+  for (uint32_t j = 0; j < nl; j++) {
+    Fr px = j == 0 ? O.x : row(5 * (j - 1));
+    Fr den = sel(j).x - px;
+    row(5 * j + 2) = prod;
+    if (!den.is_zero()) prod = prod * den;
+  }
+  inv = prod.inv();
+  for (uint32_t j = nl; j-- > 0;) {
+    GkAffine s = sel(j);
+    Fr px = j == 0 ? O.x : row(5 * (j - 1));
+    Fr py = j == 0 ? O.y : row(5 * (j - 1) + 1);
+    Fr den = s.x - px;
+    Fr lam = Fr::zero();
+    if (!den.is_zero()) {
+      Fr di = inv * row(5 * j + 2);
+      inv = inv * den;
+      lam = (s.y - py) * di;
+    }
+    W[(size_t)lw[j] * P + p] = lam;
+  }
+}
+
 __global__ void __launch_bounds__(64) k_solve(DevCircuit dc, Fr* __restrict__ W, Fr* __restrict__ scratch, uint32_t pc, uint32_t P) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
@@ -258,6 +318,12 @@ __global__ void __launch_bounds__(64) k_solve(DevCircuit dc, Fr* __restrict__ W,
         Fr s[4];
         SPP_UNROLL for (int i = 0; i < 4; i++) s[i] = dev_row_dot(dc.H, dc.coeffs, h0 + i, 0, W, P, p);
         dev_poseidon2(s, dc.p2_rc, dc.p2_mu, W, out0, P, p);
+        break;
+      }
+      case OP_GRUMPKIN: {
+        const uint32_t nl = pr[pc + 4];
+        dev_grumpkin(dc, W, scratch, pr[pc + 1], pr[pc + 2], pr[pc + 3], nl, pr + pc + 5, P, p);
+        pc += 5 + nl;
         break;
       }
       default:

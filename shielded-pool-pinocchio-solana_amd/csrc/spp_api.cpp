@@ -129,7 +129,9 @@ static hipError_t dev_upload(T** dst, const std::vector<T>& src) {
 // -----------------------------------------------------------------------------------------------------
 struct spp_ctx {
   int device;
-  hipStream_t stream;
+  hipStream_t stream;        // setup / table construction
+  hipStream_t pstream[2];    // proving: consecutive batches alternate, so the (latency-bound, few-wave) witness
+                             // solver of batch k+1 overlaps the MSMs of batch k
   std::mutex mu;
 };
 
@@ -139,9 +141,26 @@ struct MsmSet {
   Affine<F>* table = nullptr;
   uint32_t* rows = nullptr;
   bool from_h = false;   // scalars come from the h array instead of the witness
+};
+template <class F>
+struct MsmBuf {
   XYZZ<F>* partial = nullptr;
   XYZZ<F>* out = nullptr;
   size_t partial_cap = 0;   // elements allocated in `partial`
+};
+struct Workspace {
+  hipStream_t st = nullptr;
+  size_t cap = 0, last_P = 0;
+  Fr *W = nullptr, *abc = nullptr, *scratch = nullptr;
+  G1Affine* commit_affine = nullptr;
+  uint8_t *d_inputs = nullptr, *d_rs = nullptr, *d_proofs = nullptr, *d_pws = nullptr;
+  uint32_t* d_status = nullptr;
+  MsmBuf<Fq> A, B1, K, Z, CB, CS;
+  MsmBuf<Fq2> B2;
+  std::vector<void*> owned;
+  hipEvent_t ev[8] = {};
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> msm_ev;
+  size_t msm_ev_used = 0;
 };
 
 struct spp_circuit {
@@ -149,7 +168,7 @@ struct spp_circuit {
   Circuit circ;
   DevCircuit dc{};
   uint32_t c_bits = 10, n = 0, logn = 0;
-  uint32_t pc_phase2 = 0, max_batch_div = 1;
+  uint32_t pc_phase2 = 0, max_batch_div = SOLVE_SCRATCH_MIN_ROWS;
   uint32_t row_r = 0, row_s = 0, row_rs = 0, n_rows = 0;
   uint64_t table_bytes = 0;
   MsmSet<Fq> A, B1, K, Z, CB, CS;
@@ -158,17 +177,8 @@ struct spp_circuit {
   Fr zinv;
   // device copies owned here
   std::vector<void*> owned;
-  // workspace for `cap` proofs
-  size_t cap = 0, last_P = 0;
-  Fr *W = nullptr, *abc = nullptr, *scratch = nullptr;
-  G1Affine* commit_affine = nullptr;
-  uint8_t *d_inputs = nullptr, *d_rs = nullptr, *d_proofs = nullptr, *d_pws = nullptr;
-  uint32_t* d_status = nullptr;
-  std::vector<void*> ws_owned;
-  hipEvent_t ev[8] = {};
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> msm_ev;
-  size_t msm_ev_used = 0;
-  float last_ms[9] = {};
+  Workspace ws[2];
+  int next_ws = 0, last_ws = 0;
 };
 
 template <class T>
@@ -273,6 +283,8 @@ extern "C" int spp_init(int device, spp_ctx** out) {
   spp_ctx* ctx = new spp_ctx();
   ctx->device = device;
   HIP_TRY(hipStreamCreate(&ctx->stream));
+  HIP_TRY(hipStreamCreate(&ctx->pstream[0]));
+  HIP_TRY(hipStreamCreate(&ctx->pstream[1]));
   *out = ctx;
   return SPP_OK;
 }
@@ -280,6 +292,8 @@ extern "C" void spp_free_ctx(spp_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   hipStreamDestroy(ctx->stream);
+  hipStreamDestroy(ctx->pstream[0]);
+  hipStreamDestroy(ctx->pstream[1]);
   delete ctx;
 }
 
@@ -400,9 +414,11 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
       (e = upload_sparse(c, circ, circ.C, &c->dc.C)) || (e = upload_sparse(c, circ, circ.H, &c->dc.H)))
     return e;
   Fr* d_coeffs;
+  Fr* d_aux;
   uint32_t* d_prog;
-  if ((e = own_upload(c, &d_coeffs, circ.coeffs)) || (e = own_upload(c, &d_prog, circ.program))) return e;
+  if ((e = own_upload(c, &d_coeffs, circ.coeffs)) || (e = own_upload(c, &d_prog, circ.program)) || (e = own_upload(c, &d_aux, circ.aux))) return e;
   c->dc.coeffs = d_coeffs;
+  c->dc.aux = d_aux;
   c->dc.program = d_prog;
   c->dc.n_wires = circ.n_wires;
   c->dc.n_constraints = circ.n_constraints;
@@ -438,6 +454,7 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
         case OP_BITS: case OP_LIMBS8: case OP_COUNT8: case OP_POSEIDON: pc += 4; break;
         case OP_POSEIDON2: pc += 3; break;
         case OP_COMMIT: pc += 1; c->pc_phase2 = (uint32_t)pc; break;
+        case OP_GRUMPKIN: pc += 5 + pr[pc + 4]; break;
         default: return fail(SPP_ERR_FORMAT, "bad opcode %u in solver program", pr[pc]);
       }
     }
@@ -520,29 +537,36 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
   if ((e = make_set(c, &c->CB, pk.CB_w, pk.CB, false))) return e;
   if ((e = make_set(c, &c->CS, pk.CS_w, pk.CS, false))) return e;
 
-  for (auto& evt : c->ev) HIP_TRY(hipEventCreate(&evt));
-  c->msm_ev.resize(8);
-  for (auto& pr : c->msm_ev) {
-    HIP_TRY(hipEventCreate(&pr.first));
-    HIP_TRY(hipEventCreate(&pr.second));
+  for (int k = 0; k < 2; k++) {
+    Workspace& w = c->ws[k];
+    w.st = ctx->pstream[k];
+    for (auto& evt : w.ev) HIP_TRY(hipEventCreate(&evt));
+    w.msm_ev.resize(8);
+    for (auto& pr : w.msm_ev) {
+      HIP_TRY(hipEventCreate(&pr.first));
+      HIP_TRY(hipEventCreate(&pr.second));
+    }
   }
   *out = c;
   return SPP_OK;
 }
 
-static void free_workspace(spp_circuit* c) {
-  for (void* p : c->ws_owned) hipFree(p);
-  c->ws_owned.clear();
-  c->cap = 0;
+static void free_workspace(Workspace& w) {
+  for (void* p : w.owned) hipFree(p);
+  w.owned.clear();
+  w.cap = 0;
 }
 extern "C" void spp_free_circuit(spp_circuit* c) {
   if (!c) return;
   hipSetDevice(c->ctx->device);
   hipStreamSynchronize(c->ctx->stream);
-  free_workspace(c);
+  for (auto& w : c->ws) {
+    if (w.st) hipStreamSynchronize(w.st);
+    free_workspace(w);
+    for (auto& evt : w.ev) if (evt) hipEventDestroy(evt);
+    for (auto& pr : w.msm_ev) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+  }
   for (void* p : c->owned) hipFree(p);
-  for (auto& evt : c->ev) if (evt) hipEventDestroy(evt);
-  for (auto& pr : c->msm_ev) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   delete c;
 }
 extern "C" int spp_circuit_info(const spp_circuit* c, uint32_t info[8]) {
@@ -559,98 +583,100 @@ extern "C" int spp_circuit_msm_sizes(const spp_circuit* c, uint32_t sizes[7]) {
 }
 
 template <class T>
-static int ws_alloc(spp_circuit* c, T** p, size_t count) {
+static int ws_alloc(Workspace& w, T** p, size_t count) {
   HIP_TRY(hipMalloc((void**)p, sizeof(T) * std::max<size_t>(count, 1)));
-  c->ws_owned.push_back((void*)*p);
+  w.owned.push_back((void*)*p);
   return 0;
 }
 template <class F>
-static int ws_set(spp_circuit* c, MsmSet<F>* s, size_t P) {
+static int ws_set(Workspace& w, const MsmSet<F>* s, MsmBuf<F>* b, size_t P) {
   // S(P')*P' <= min(target + P', ceil(N/4)*P') for every P' <= P
   size_t max_s = std::max<size_t>((s->N + 3) / 4, 1);
-  s->partial_cap = std::min<size_t>((size_t)256 * 4 * 4 * 64 + P, max_s * P);
-  s->partial_cap = std::max<size_t>(s->partial_cap, (size_t)msm_slices(s->N, (uint32_t)P) * P);
+  b->partial_cap = std::min<size_t>((size_t)256 * 4 * 4 * 64 + P, max_s * P);
+  b->partial_cap = std::max<size_t>(b->partial_cap, (size_t)msm_slices(s->N, (uint32_t)P) * P);
   int e;
-  if ((e = ws_alloc(c, &s->partial, s->partial_cap))) return e;
-  return ws_alloc(c, &s->out, P);
+  if ((e = ws_alloc(w, &b->partial, b->partial_cap))) return e;
+  return ws_alloc(w, &b->out, P);
 }
-static int ensure_workspace(spp_circuit* c, size_t P) {
-  if (P <= c->cap) return 0;
-  free_workspace(c);
+static int ensure_workspace(spp_circuit* c, Workspace& w, size_t P) {
+  if (P <= w.cap) return 0;
+  HIP_TRY(hipStreamSynchronize(w.st));
+  free_workspace(w);
   int e;
   const size_t npub = c->circ.n_public - 1;
-  if ((e = ws_alloc(c, &c->W, (size_t)c->n_rows * P)) || (e = ws_alloc(c, &c->abc, (size_t)3 * c->n * P)) ||
-      (e = ws_alloc(c, &c->scratch, (size_t)c->max_batch_div * P)) || (e = ws_alloc(c, &c->commit_affine, P)) ||
-      (e = ws_alloc(c, &c->d_inputs, (size_t)c->circ.n_inputs() * 32 * P)) || (e = ws_alloc(c, &c->d_rs, 64 * P)) ||
-      (e = ws_alloc(c, &c->d_proofs, (size_t)SPP_PROOF_LEN * P)) || (e = ws_alloc(c, &c->d_pws, (12 + 32 * npub) * P)) ||
-      (e = ws_alloc(c, &c->d_status, P)))
+  if ((e = ws_alloc(w, &w.W, (size_t)c->n_rows * P)) || (e = ws_alloc(w, &w.abc, (size_t)3 * c->n * P)) ||
+      (e = ws_alloc(w, &w.scratch, (size_t)c->max_batch_div * P)) || (e = ws_alloc(w, &w.commit_affine, P)) ||
+      (e = ws_alloc(w, &w.d_inputs, (size_t)c->circ.n_inputs() * 32 * P)) || (e = ws_alloc(w, &w.d_rs, 64 * P)) ||
+      (e = ws_alloc(w, &w.d_proofs, (size_t)SPP_PROOF_LEN * P)) || (e = ws_alloc(w, &w.d_pws, (12 + 32 * npub) * P)) ||
+      (e = ws_alloc(w, &w.d_status, P)))
     return e;
-  if ((e = ws_set(c, &c->A, P)) || (e = ws_set(c, &c->B1, P)) || (e = ws_set(c, &c->B2, P)) || (e = ws_set(c, &c->K, P)) ||
-      (e = ws_set(c, &c->Z, P)) || (e = ws_set(c, &c->CB, P)) || (e = ws_set(c, &c->CS, P)))
+  if ((e = ws_set(w, &c->A, &w.A, P)) || (e = ws_set(w, &c->B1, &w.B1, P)) || (e = ws_set(w, &c->B2, &w.B2, P)) ||
+      (e = ws_set(w, &c->K, &w.K, P)) || (e = ws_set(w, &c->Z, &w.Z, P)) || (e = ws_set(w, &c->CB, &w.CB, P)) ||
+      (e = ws_set(w, &c->CS, &w.CS, P)))
     return e;
-  c->cap = P;
+  w.cap = P;
   return 0;
 }
 
 template <class F>
-static void run_msm(spp_circuit* c, MsmSet<F>& s, uint32_t P, bool timed) {
-  hipStream_t st = c->ctx->stream;
-  const Fr* scal = s.from_h ? c->abc : c->W;
+static void run_msm(spp_circuit* c, Workspace& w, const MsmSet<F>& s, MsmBuf<F>& b, uint32_t P, bool timed) {
+  hipStream_t st = w.st;
+  const Fr* scal = s.from_h ? w.abc : w.W;
   uint32_t S = msm_slices(s.N, P);
-  while (S > 1 && (size_t)S * P > s.partial_cap) S--;  // never exceed the allocated partial buffer
+  while (S > 1 && (size_t)S * P > b.partial_cap) S--;  // never exceed the allocated partial buffer
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
-  if (timed && c->msm_ev_used < c->msm_ev.size()) ev = &c->msm_ev[c->msm_ev_used++];
+  if (timed && w.msm_ev_used < w.msm_ev.size()) ev = &w.msm_ev[w.msm_ev_used++];
   if (ev) hipEventRecord(ev->first, st);
-  launch_msm_accumulate<F>(st, s.table, s.rows, scal, s.partial, s.N, P, c->c_bits, S);
+  launch_msm_accumulate<F>(st, s.table, s.rows, scal, b.partial, s.N, P, c->c_bits, S);
   if (ev) hipEventRecord(ev->second, st);
-  launch_msm_reduce<F>(st, s.partial, s.out, P, s.N ? S : 0);
+  launch_msm_reduce<F>(st, b.partial, b.out, P, s.N ? S : 0);
 }
 
-static int prove_on_device(spp_circuit* c, uint32_t P, const uint8_t* d_inputs, const uint8_t* d_rs, uint8_t* d_proofs, uint8_t* d_pws,
-                           uint32_t* d_status) {
-  hipStream_t st = c->ctx->stream;
+static int prove_on_device(spp_circuit* c, Workspace& w, uint32_t P, const uint8_t* d_inputs, const uint8_t* d_rs, uint8_t* d_proofs,
+                           uint8_t* d_pws, uint32_t* d_status) {
+  hipStream_t st = w.st;
   const Circuit& circ = c->circ;
   const uint32_t n = c->n;
-  c->msm_ev_used = 0;
-  c->last_P = P;
+  w.msm_ev_used = 0;
+  w.last_P = P;
   HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(uint32_t) * P, st));
-  hipEventRecord(c->ev[0], st);
+  hipEventRecord(w.ev[0], st);
   // 1. inputs, solver phase 1, commitment, challenge, solver phase 2
-  launch_load_inputs(st, d_inputs, d_rs, c->W, circ.n_inputs(), circ.n_wires, P);
-  launch_solve(st, c->dc, c->W, c->scratch, 0, P);
-  run_msm(c, c->CB, P, true);
-  launch_challenge(st, c->CB.out, c->W, circ.challenge_wire, P, c->commit_affine, d_status);
-  launch_solve(st, c->dc, c->W, c->scratch, c->pc_phase2, P);
-  hipEventRecord(c->ev[1], st);
+  launch_load_inputs(st, d_inputs, d_rs, w.W, circ.n_inputs(), circ.n_wires, P);
+  launch_solve(st, c->dc, w.W, w.scratch, 0, P);
+  run_msm(c, w, c->CB, w.CB, P, true);
+  launch_challenge(st, w.CB.out, w.W, circ.challenge_wire, P, w.commit_affine, d_status);
+  launch_solve(st, c->dc, w.W, w.scratch, c->pc_phase2, P);
+  hipEventRecord(w.ev[1], st);
   // 2. constraint evaluations + satisfaction check
-  launch_spmv_check(st, c->dc, c->W, c->abc, n, P, d_status);
-  hipEventRecord(c->ev[2], st);
+  launch_spmv_check(st, c->dc, w.W, w.abc, n, P, d_status);
+  hipEventRecord(w.ev[2], st);
   // 3. h = (a*b - c)/Z  (coefficients land bit-reversed in the a-slot of abc)
   const size_t bs = (size_t)n * P;
-  launch_ntt(st, c->abc, c->logn, P, c->tw_inv, true, 3, bs);
-  launch_scale_rows(st, c->abc, c->coset_br, n, P, 3, bs);
-  launch_ntt(st, c->abc, c->logn, P, c->tw_fwd, false, 3, bs);
-  launch_qap_pointwise(st, c->abc, n, P, c->zinv);
-  launch_ntt(st, c->abc, c->logn, P, c->tw_inv, true, 1, bs);
-  launch_scale_rows(st, c->abc, c->coset_inv_br, n, P, 1, bs);
-  hipEventRecord(c->ev[3], st);
+  launch_ntt(st, w.abc, c->logn, P, c->tw_inv, true, 3, bs);
+  launch_scale_rows(st, w.abc, c->coset_br, n, P, 3, bs);
+  launch_ntt(st, w.abc, c->logn, P, c->tw_fwd, false, 3, bs);
+  launch_qap_pointwise(st, w.abc, n, P, c->zinv);
+  launch_ntt(st, w.abc, c->logn, P, c->tw_inv, true, 1, bs);
+  launch_scale_rows(st, w.abc, c->coset_inv_br, n, P, 1, bs);
+  hipEventRecord(w.ev[3], st);
   // 4. MSMs
-  run_msm(c, c->A, P, true);
-  run_msm(c, c->B1, P, true);
-  run_msm(c, c->K, P, true);
-  run_msm(c, c->Z, P, true);
-  run_msm(c, c->CS, P, true);
-  hipEventRecord(c->ev[4], st);
-  run_msm(c, c->B2, P, false);
-  hipEventRecord(c->ev[5], st);
+  run_msm(c, w, c->A, w.A, P, true);
+  run_msm(c, w, c->B1, w.B1, P, true);
+  run_msm(c, w, c->K, w.K, P, true);
+  run_msm(c, w, c->Z, w.Z, P, true);
+  run_msm(c, w, c->CS, w.CS, P, true);
+  hipEventRecord(w.ev[4], st);
+  run_msm(c, w, c->B2, w.B2, P, false);
+  hipEventRecord(w.ev[5], st);
   // 5. assembly
   AssembleArgs a;
-  a.mA = c->A.out; a.mB1 = c->B1.out; a.mB2 = c->B2.out; a.mK = c->K.out; a.mZ = c->Z.out; a.mPok = c->CS.out;
-  a.commit_affine = c->commit_affine;
-  a.W = c->W; a.row_r = c->row_r; a.row_s = c->row_s; a.n_public = circ.n_public;
+  a.mA = w.A.out; a.mB1 = w.B1.out; a.mB2 = w.B2.out; a.mK = w.K.out; a.mZ = w.Z.out; a.mPok = w.CS.out;
+  a.commit_affine = w.commit_affine;
+  a.W = w.W; a.row_r = c->row_r; a.row_s = c->row_s; a.n_public = circ.n_public;
   a.proofs = d_proofs; a.pws = d_pws; a.P = P;
   launch_assemble(st, a);
-  hipEventRecord(c->ev[6], st);
+  hipEventRecord(w.ev[6], st);
   HIP_TRY(hipGetLastError());
   return SPP_OK;
 }
@@ -662,36 +688,43 @@ extern "C" int spp_prove_batch_device(spp_circuit* c, size_t count, const void* 
   if (count > (1u << 20)) return fail(SPP_ERR_BAD_INPUT, "batch too large");
   std::lock_guard<std::mutex> lk(c->ctx->mu);
   HIP_TRY(hipSetDevice(c->ctx->device));
-  if (int e = ensure_workspace(c, count)) return e;
-  return prove_on_device(c, (uint32_t)count, (const uint8_t*)d_inputs, (const uint8_t*)d_rs, (uint8_t*)d_proofs, (uint8_t*)d_pws,
+  Workspace& w = c->ws[c->next_ws];
+  c->last_ws = c->next_ws;
+  c->next_ws ^= 1;
+  if (int e = ensure_workspace(c, w, count)) return e;
+  return prove_on_device(c, w, (uint32_t)count, (const uint8_t*)d_inputs, (const uint8_t*)d_rs, (uint8_t*)d_proofs, (uint8_t*)d_pws,
                          (uint32_t*)d_status);
 }
 extern "C" int spp_sync(spp_circuit* c) {
   if (!c) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
   HIP_TRY(hipSetDevice(c->ctx->device));
-  HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+  HIP_TRY(hipStreamSynchronize(c->ws[0].st));
+  HIP_TRY(hipStreamSynchronize(c->ws[1].st));
   return SPP_OK;
 }
-extern "C" int spp_last_timings(spp_circuit* c, float ms[9]) {
+extern "C" int spp_last_timings(spp_circuit* c, float ms[9]) { return spp_timings(c, 0, ms); }
+extern "C" int spp_timings(spp_circuit* c, int which, float ms[9]) {
   if (!c || !ms) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
   HIP_TRY(hipSetDevice(c->ctx->device));
-  HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+  Workspace& w = c->ws[which ? c->last_ws ^ 1 : c->last_ws];
+  if (w.cap == 0) return fail(SPP_ERR_BAD_INPUT, "no such batch");
+  HIP_TRY(hipStreamSynchronize(w.st));
   for (int i = 0; i < 6; i++) {
     float t = 0;
-    HIP_TRY(hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]));
+    HIP_TRY(hipEventElapsedTime(&t, w.ev[i], w.ev[i + 1]));
     ms[i] = t;
   }
   float tot = 0;
-  HIP_TRY(hipEventElapsedTime(&tot, c->ev[0], c->ev[6]));
+  HIP_TRY(hipEventElapsedTime(&tot, w.ev[0], w.ev[6]));
   ms[6] = tot;
   float sum = 0;
-  for (size_t i = 0; i < c->msm_ev_used; i++) {
+  for (size_t i = 0; i < w.msm_ev_used; i++) {
     float t = 0;
-    HIP_TRY(hipEventElapsedTime(&t, c->msm_ev[i].first, c->msm_ev[i].second));
+    HIP_TRY(hipEventElapsedTime(&t, w.msm_ev[i].first, w.msm_ev[i].second));
     sum += t;
   }
-  ms[7] = c->msm_ev_used ? sum / (float)c->msm_ev_used : 0.f;
-  ms[8] = (float)c->msm_ev_used;
+  ms[7] = w.msm_ev_used ? sum / (float)w.msm_ev_used : 0.f;
+  ms[8] = (float)w.msm_ev_used;
   return SPP_OK;
 }
 
@@ -714,15 +747,18 @@ extern "C" int spp_prove_batch(spp_circuit* c, size_t count, const uint8_t* inpu
   {
     std::lock_guard<std::mutex> lk(c->ctx->mu);
     HIP_TRY(hipSetDevice(c->ctx->device));
-    if (int e = ensure_workspace(c, count)) return e;
-    hipStream_t s = c->ctx->stream;
+    Workspace& w = c->ws[c->next_ws];
+    c->last_ws = c->next_ws;
+    c->next_ws ^= 1;
+    if (int e = ensure_workspace(c, w, count)) return e;
+    hipStream_t s = w.st;
     const size_t nin = c->circ.n_inputs(), npub = c->circ.n_public - 1;
-    HIP_TRY(hipMemcpyAsync(c->d_inputs, inputs, nin * 32 * count, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(c->d_rs, rs, 64 * count, hipMemcpyHostToDevice, s));
-    if (int e = prove_on_device(c, (uint32_t)count, c->d_inputs, c->d_rs, c->d_proofs, c->d_pws, c->d_status)) return e;
-    HIP_TRY(hipMemcpyAsync(proofs, c->d_proofs, (size_t)SPP_PROOF_LEN * count, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(pws, c->d_pws, (12 + 32 * npub) * count, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(st.data(), c->d_status, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(w.d_inputs, inputs, nin * 32 * count, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(w.d_rs, rs, 64 * count, hipMemcpyHostToDevice, s));
+    if (int e = prove_on_device(c, w, (uint32_t)count, w.d_inputs, w.d_rs, w.d_proofs, w.d_pws, w.d_status)) return e;
+    HIP_TRY(hipMemcpyAsync(proofs, w.d_proofs, (size_t)SPP_PROOF_LEN * count, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(pws, w.d_pws, (12 + 32 * npub) * count, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(st.data(), w.d_status, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
   }
   int rc = SPP_OK;
@@ -751,13 +787,14 @@ extern "C" int spp_prove_withdraw(spp_circuit* c, const spp_withdraw_inputs* in,
 
 extern "C" int spp_debug_witness(spp_circuit* c, uint8_t* out, size_t n_wires) {
   if (!c || !out) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
-  if (c->cap == 0) return fail(SPP_ERR_BAD_INPUT, "no batch has been proved yet");
+  Workspace& w = c->ws[c->last_ws];
+  if (w.cap == 0) return fail(SPP_ERR_BAD_INPUT, "no batch has been proved yet");
   std::lock_guard<std::mutex> lk(c->ctx->mu);
   HIP_TRY(hipSetDevice(c->ctx->device));
-  HIP_TRY(hipStreamSynchronize(c->ctx->stream));
-  size_t P = c->last_P;   // column 0 of W at the stride of the last batch
+  HIP_TRY(hipStreamSynchronize(w.st));
+  size_t P = w.last_P;   // column 0 of W at the stride of the last batch
   std::vector<Fr> col(std::min<size_t>(n_wires, c->circ.n_wires));
-  for (size_t i = 0; i < col.size(); i++) HIP_TRY(hipMemcpy(&col[i], c->W + i * P, sizeof(Fr), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < col.size(); i++) HIP_TRY(hipMemcpy(&col[i], w.W + i * P, sizeof(Fr), hipMemcpyDeviceToHost));
   for (size_t i = 0; i < col.size(); i++) col[i].to_bytes_be(out + 32 * i);
   return SPP_OK;
 }

@@ -54,6 +54,7 @@ def load_library():
     L.spp_prove_batch_device.argtypes = [vp, sz, vp, vp, vp, vp, vp]
     L.spp_sync.argtypes = [vp]
     L.spp_last_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    L.spp_timings.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_float)]
     L.spp_prove_withdraw.argtypes = [vp, ctypes.POINTER(WithdrawInputs), cp, vp, vp]
     L.spp_debug_witness.argtypes = [vp, vp, sz]
     L.spp_ntt_fr.argtypes = [vp, vp, u32, i32]

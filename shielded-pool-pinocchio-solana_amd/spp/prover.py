@@ -103,9 +103,10 @@ class CircuitHandle:
     def sync(self):
         check(self.L.spp_sync(self.h))
 
-    def last_timings(self):
+    def last_timings(self, which=0):
+        """which=0: last enqueued batch; 1: the batch before it (see spp_timings in include/spp.h)."""
         ms = (ctypes.c_float * 9)()
-        check(self.L.spp_last_timings(self.h, ms))
+        check(self.L.spp_timings(self.h, int(which), ms))
         return list(ms)
 
     def debug_witness(self):
