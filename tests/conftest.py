@@ -44,3 +44,16 @@ def withdraw_artifacts(workdir):
     n = spp.build_circuit(1, sppc)
     native.setup(sppc, b"\x07" * 32, pk, vk)
     return dict(sppc=sppc, pk=pk, vk=vk, n_constraints=n)
+
+
+@pytest.fixture(scope="session")
+def audit_artifacts(workdir, rlwe_pk):
+    """Audit SPPC from the product's builder over the reference's rlwe_pk.json; pk/vk from the oracle's CPU setup."""
+    import spp
+    from oracle import native
+    sppc = os.path.join(workdir, "audit.sppc")
+    pk = os.path.join(workdir, "audit.pk")
+    vk = os.path.join(workdir, "audit.vk")
+    n = spp.build_circuit(2, sppc, aux=list(rlwe_pk["a"]) + list(rlwe_pk["b"]))
+    native.setup(sppc, b"\x09" * 32, pk, vk)
+    return dict(sppc=sppc, pk=pk, vk=vk, n_constraints=n)

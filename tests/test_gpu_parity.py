@@ -156,3 +156,40 @@ def test_odd_batch_sizes_and_default_window(ctx, withdraw_artifacts, withdraw_ka
                 assert proofs[i] == proof and pws[i] == pw, (count, i)
     finally:
         h.close()
+
+
+# ---------------------------------------------------------------------------------------------- audit circuit
+def _audit_rows(rlwe_pk, count):
+    from oracle import rlwe
+    rows = []
+    for i in range(count):
+        # instance 0 = the reference's own run: sk 12345, Random(999) (scripts/generate_audit.py:469-470)
+        d = rlwe.audit_inputs(rlwe_pk["a"], rlwe_pk["b"], 12345 + i, random.Random(999 + i))
+        rows.append(rlwe.audit_input_vector(d))
+    return rows
+
+
+def test_audit_proof_bytes_match_oracle_and_verify(ctx, audit_artifacts, rlwe_pk):
+    from oracle import native, groth16
+    assert 20000 < audit_artifacts["n_constraints"] < 32768      # README.md:49 quotes ~26K
+    h = ctx.load_circuit(audit_artifacts["sppc"], audit_artifacts["pk"], 6)
+    try:
+        rows = _audit_rows(rlwe_pk, 3)
+        rs = [(11 + i, 13 + 5 * i) for i in range(3)]
+        proofs, pws, status = h.prove_batch(rows, rs)
+        assert status == [0, 0, 0]
+        orc = native.Prover(audit_artifacts["sppc"], audit_artifacts["pk"])
+        vk = open(audit_artifacts["vk"], "rb").read()
+        assert len(vk) == 1104                                   # size of the reference's rlwe_audit.vk
+        for i in range(3):
+            rc, proof, pw = orc.prove(rows[i], rs[i][0], rs[i][1])
+            assert rc == 0 and len(pw) == 76                     # submit_audit.rs:19-21
+            assert pws[i] == pw and proofs[i] == proof, "audit proof %d differs from the oracle" % i
+        assert groth16.verify(vk, proofs[0], pws[0])
+        # noise out of range / tampered ciphertext commitment are refused
+        bad_r = list(rows[0]); bad_r[2 + 157 + 1 + 7] = 200
+        bad_ct = list(rows[0]); bad_ct[1] += 1
+        _, _, st = h.prove_batch([rows[1], bad_r, bad_ct], [(1, 2)] * 3)
+        assert st == [0, -4, -4]
+    finally:
+        h.close()
