@@ -24,6 +24,33 @@
 
 namespace spp {
 
+// add / subtract with carry: clang's multiprecision builtins lower to v_addc_co_u32 / v_subb_co_u32 chains
+// on gfx950 (a 64-bit emulation costs ~4x the instructions); plain C for other host compilers.
+SPP_HD uint32_t addc32(uint32_t a, uint32_t b, uint32_t& carry) {
+#if defined(__clang__)
+  unsigned co;
+  uint32_t r = __builtin_addc(a, b, carry, &co);
+  carry = co;
+  return r;
+#else
+  uint64_t t = (uint64_t)a + b + carry;
+  carry = (uint32_t)(t >> 32);
+  return (uint32_t)t;
+#endif
+}
+SPP_HD uint32_t subb32(uint32_t a, uint32_t b, uint32_t& borrow) {
+#if defined(__clang__)
+  unsigned bo;
+  uint32_t r = __builtin_subc(a, b, borrow, &bo);
+  borrow = bo;
+  return r;
+#else
+  uint64_t t = (uint64_t)a - b - borrow;
+  borrow = (uint32_t)(t >> 63);
+  return (uint32_t)t;
+#endif
+}
+
 // --------------------------------------------------------------------------------------------------
 // Fp<Params>: element of GF(p) in Montgomery form (value * 2^256 mod p), always fully reduced (< p).
 // --------------------------------------------------------------------------------------------------
@@ -66,96 +93,140 @@ struct Fp {
   // raw limbs >= modulus ?
   static SPP_HD bool geq_mod(const uint32_t* a) {
     // compute a - p, look at the borrow
-    uint64_t br = 0;
-    SPP_UNROLL for (int i = 0; i < 8; i++) {
-      uint64_t d = (uint64_t)a[i] - Pm::MOD(i) - br;
-      br = (d >> 63) & 1;
-    }
+    uint32_t br = 0;
+    SPP_UNROLL for (int i = 0; i < 8; i++) (void)subb32(a[i], Pm::MOD(i), br);
     return br == 0;
   }
   // r = a - p if a >= p (a < 2p)
   static SPP_HD void cond_sub(uint32_t* a) {
     uint32_t t[8];
-    uint64_t br = 0;
-    SPP_UNROLL for (int i = 0; i < 8; i++) {
-      uint64_t d = (uint64_t)a[i] - Pm::MOD(i) - br;
-      t[i] = (uint32_t)d;
-      br = (d >> 63) & 1;
-    }
-    if (br == 0) {
-      SPP_UNROLL for (int i = 0; i < 8; i++) a[i] = t[i];
-    }
+    uint32_t br = 0;
+    SPP_UNROLL for (int i = 0; i < 8; i++) t[i] = subb32(a[i], Pm::MOD(i), br);
+    SPP_UNROLL for (int i = 0; i < 8; i++) a[i] = br ? a[i] : t[i];
   }
 
   friend SPP_HD Fp operator+(const Fp& a, const Fp& b) {
     Fp r;
-    uint64_t c = 0;
-    SPP_UNROLL for (int i = 0; i < 8; i++) {
-      c += (uint64_t)a.l[i] + b.l[i];
-      r.l[i] = (uint32_t)c;
-      c >>= 32;
-    }
+    uint32_t c = 0;
+    SPP_UNROLL for (int i = 0; i < 8; i++) r.l[i] = addc32(a.l[i], b.l[i], c);
     // p < 2^254 so a+b < 2^255: no carry out of limb 7
     cond_sub(r.l);
     return r;
   }
   friend SPP_HD Fp operator-(const Fp& a, const Fp& b) {
     Fp r;
-    uint64_t br = 0;
-    SPP_UNROLL for (int i = 0; i < 8; i++) {
-      uint64_t d = (uint64_t)a.l[i] - b.l[i] - br;
-      r.l[i] = (uint32_t)d;
-      br = (d >> 63) & 1;
-    }
-    if (br) {
-      uint64_t c = 0;
-      SPP_UNROLL for (int i = 0; i < 8; i++) {
-        c += (uint64_t)r.l[i] + Pm::MOD(i);
-        r.l[i] = (uint32_t)c;
-        c >>= 32;
-      }
-    }
+    uint32_t br = 0;
+    SPP_UNROLL for (int i = 0; i < 8; i++) r.l[i] = subb32(a.l[i], b.l[i], br);
+    // add p back when the difference went negative (mask form: no divergent branch)
+    const uint32_t mask = 0u - br;
+    uint32_t c = 0;
+    SPP_UNROLL for (int i = 0; i < 8; i++) r.l[i] = addc32(r.l[i], Pm::MOD(i) & mask, c);
     return r;
   }
   SPP_HD Fp neg() const {
     if (is_zero()) return *this;
     Fp r;
-    uint64_t br = 0;
-    SPP_UNROLL for (int i = 0; i < 8; i++) {
-      uint64_t d = (uint64_t)Pm::MOD(i) - l[i] - br;
-      r.l[i] = (uint32_t)d;
-      br = (d >> 63) & 1;
-    }
+    uint32_t br = 0;
+    SPP_UNROLL for (int i = 0; i < 8; i++) r.l[i] = subb32(Pm::MOD(i), l[i], br);
     return r;
   }
   SPP_HD Fp dbl() const { return *this + *this; }
 
-  // Montgomery product, CIOS fused with the reduction (valid because p < 2^254: no extra carry word).
-  friend SPP_HD Fp operator*(const Fp& a, const Fp& b) {
-    uint32_t t[8];
-    SPP_UNROLL for (int i = 0; i < 8; i++) t[i] = 0;
-    SPP_UNROLL for (int i = 0; i < 8; i++) {
-      const uint32_t bi = b.l[i];
-      uint64_t A = (uint64_t)a.l[0] * bi + t[0];
-      const uint32_t m = (uint32_t)A * Pm::INV32;
-      uint64_t C = (uint64_t)m * Pm::MOD(0) + (uint32_t)A;
-      A >>= 32;
-      C >>= 32;
-      SPP_UNROLL for (int j = 1; j < 8; j++) {
-        A += (uint64_t)a.l[j] * bi + t[j];
-        C += (uint64_t)m * Pm::MOD(j) + (uint32_t)A;
-        t[j - 1] = (uint32_t)C;
-        A >>= 32;
-        C >>= 32;
-      }
-      t[7] = (uint32_t)(A + C);
+  // ---- Montgomery multiplication -----------------------------------------------------------------
+  // Measured on gfx950 (tests/micro/valu_rates.hip): v_mad_u64_u32 issues at the same rate as v_mul_lo_u32 or a
+  // 64-bit add (~4.5 cycles per wave-instruction), so what matters is the instruction count around the 32x32
+  // products.  A word-serial CIOS on saturated 32-bit limbs needs a carry fix-up (and register-pair shuffles)
+  // after every product: ~600 instructions.  Instead the operands are re-sliced into 9 limbs of 29 bits: the 81
+  // partial products then accumulate into 17 independent 64-bit columns with one v_mad_u64_u32 each and no
+  // carries at all (9 * 2^58 * 2 < 2^63), and the Montgomery reduction adds m_k * p the same way.  Eight
+  // reduction steps clear 29 bits each and a ninth clears 24, so the result is still a*b/2^256: the memory format
+  // and every constant stay those of the 8 x 32-bit representation.
+  static constexpr uint32_t M29 = (1u << 29) - 1u;
+  static SPP_HD constexpr uint32_t P9(int k) {
+    // limb k (29 bits) of the modulus
+    const int bit = 29 * k, w = bit / 32, o = bit % 32;
+    uint64_t v = Pm::MOD(w);
+    if (w + 1 < 8) v |= (uint64_t)Pm::MOD(w + 1) << 32;
+    return (uint32_t)(v >> o) & M29;
+  }
+  static SPP_HD void to9(const uint32_t w[8], uint32_t o[9]) {
+    o[0] = w[0] & M29;
+    o[1] = ((w[0] >> 29) | (w[1] << 3)) & M29;
+    o[2] = ((w[1] >> 26) | (w[2] << 6)) & M29;
+    o[3] = ((w[2] >> 23) | (w[3] << 9)) & M29;
+    o[4] = ((w[3] >> 20) | (w[4] << 12)) & M29;
+    o[5] = ((w[4] >> 17) | (w[5] << 15)) & M29;
+    o[6] = ((w[5] >> 14) | (w[6] << 18)) & M29;
+    o[7] = ((w[6] >> 11) | (w[7] << 21)) & M29;
+    o[8] = w[7] >> 8;
+    hide24(o[8]);
+  }
+  // Values the compiler can prove to be < 2^24 make it select v_mul_u32_u24 / v_mul_hi_u32_u24 and drop the
+  // masking AND; on gfx950 (ROCm 7.2) the high half then came back wrong (tests/micro/device_arith_check.hip,
+  // dbg_mul.hip).  An empty asm hides the range so the product stays a v_mad_u64_u32.
+  static SPP_HD void hide24(uint32_t& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v));
+#else
+    (void)v;
+#endif
+  }
+  // c[0..17]: column sums of the double-width product -> reduced, repacked result
+  static SPP_HD Fp reduce_columns(uint64_t (&c)[18]) {
+    SPP_UNROLL for (int k = 0; k < 8; k++) {
+      const uint32_t m = ((uint32_t)c[k] * Pm::INV32) & M29;
+      SPP_UNROLL for (int j = 0; j < 9; j++) c[k + j] += (uint64_t)m * P9(j);
+      c[k + 1] += c[k] >> 29;
     }
+    {
+      uint32_t m = ((uint32_t)c[8] * Pm::INV32) & ((1u << 24) - 1u);
+      hide24(m);
+      SPP_UNROLL for (int j = 0; j < 9; j++) c[8 + j] += (uint64_t)m * P9(j);
+    }
+    // result = (c[8] >> 24) + c[9]*2^5 + c[10]*2^34 + ... + c[17]*2^237 ; normalise the columns to 29 bits
+    const uint32_t lo5 = (uint32_t)(c[8] >> 24) & 31u;
+    c[9] += c[8] >> 29;
+    uint32_t n[9];
+    SPP_UNROLL for (int k = 0; k < 8; k++) {
+      n[k] = (uint32_t)c[9 + k] & M29;
+      c[10 + k] += c[9 + k] >> 29;
+    }
+    n[8] = (uint32_t)c[17];
     Fp r;
-    SPP_UNROLL for (int i = 0; i < 8; i++) r.l[i] = t[i];
+    r.l[0] = lo5 | (n[0] << 5);
+    r.l[1] = (n[0] >> 27) | (n[1] << 2) | (n[2] << 31);
+    r.l[2] = (n[2] >> 1) | (n[3] << 28);
+    r.l[3] = (n[3] >> 4) | (n[4] << 25);
+    r.l[4] = (n[4] >> 7) | (n[5] << 22);
+    r.l[5] = (n[5] >> 10) | (n[6] << 19);
+    r.l[6] = (n[6] >> 13) | (n[7] << 16);
+    r.l[7] = (n[7] >> 16) | (n[8] << 13);
     cond_sub(r.l);
     return r;
   }
-  SPP_HD Fp sqr() const { return *this * *this; }
+  friend SPP_HD Fp operator*(const Fp& a, const Fp& b) {
+    uint32_t a9[9], b9[9];
+    to9(a.l, a9);
+    to9(b.l, b9);
+    uint64_t c[18];
+    SPP_UNROLL for (int k = 0; k < 18; k++) c[k] = 0;
+    SPP_UNROLL for (int i = 0; i < 9; i++) {
+      SPP_UNROLL for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)a9[i] * b9[j];
+    }
+    return reduce_columns(c);
+  }
+  SPP_HD Fp sqr() const {
+    uint32_t a9[9], d9[9];
+    to9(l, a9);
+    SPP_UNROLL for (int i = 0; i < 9; i++) d9[i] = a9[i] << 1;
+    uint64_t c[18];
+    SPP_UNROLL for (int k = 0; k < 18; k++) c[k] = 0;
+    SPP_UNROLL for (int i = 0; i < 9; i++) {
+      c[2 * i] += (uint64_t)a9[i] * a9[i];
+      SPP_UNROLL for (int j = i + 1; j < 9; j++) c[i + j] += (uint64_t)a9[i] * d9[j];
+    }
+    return reduce_columns(c);
+  }
 
   // multiply by a small unsigned constant (k < 2^16) via double-and-add on the bits of k
   SPP_HD Fp mul_small(uint32_t k) const {
@@ -249,22 +320,15 @@ using Fq = Fp<FqParams>;
 template <class Pm>
 SPP_HD bool canonical_gt_half(const uint32_t c[8]) {
   // HALF - c < 0  <=>  c > HALF
-  uint64_t br = 0;
-  SPP_UNROLL for (int i = 0; i < 8; i++) {
-    uint64_t d = (uint64_t)Pm::HALF(i) - c[i] - br;
-    br = (d >> 63) & 1;
-  }
+  uint32_t br = 0;
+  SPP_UNROLL for (int i = 0; i < 8; i++) (void)subb32(Pm::HALF(i), c[i], br);
   return br != 0;
 }
 // out = p - c  (c canonical, nonzero)
 template <class Pm>
 SPP_HD void canonical_negate(const uint32_t c[8], uint32_t out[8]) {
-  uint64_t br = 0;
-  SPP_UNROLL for (int i = 0; i < 8; i++) {
-    uint64_t d = (uint64_t)Pm::MOD(i) - c[i] - br;
-    out[i] = (uint32_t)d;
-    br = (d >> 63) & 1;
-  }
+  uint32_t br = 0;
+  SPP_UNROLL for (int i = 0; i < 8; i++) out[i] = subb32(Pm::MOD(i), c[i], br);
 }
 
 // --------------------------------------------------------------------------------------------------
