@@ -32,6 +32,7 @@ struct DevCircuit {
   const Fr* pos3_rc;  const Fr* pos3_mds;   // t=3: 195 rc, 9 mds (row-major)
   const Fr* pos5_rc;  const Fr* pos5_mds;   // t=5: 340 rc, 25 mds
   const Fr* p2_rc;    const Fr* p2_mu;      // 88 rc, 4 mu
+  const Fr* byte_mont;                      // Montgomery forms of 0..255
 };
 
 // ---- witness ----
@@ -39,7 +40,10 @@ void launch_load_inputs(hipStream_t st, const uint8_t* d_inputs_be, const uint8_
                         uint32_t n_wires, uint32_t P);
 // runs the solver program from word `pc` until OP_COMMIT / OP_END; scratch: [SOLVE_SCRATCH_ROWS or more][P] Fr
 static constexpr uint32_t SOLVE_SCRATCH_MIN_ROWS = 324;
-void launch_solve(hipStream_t st, DevCircuit dc, Fr* W, Fr* scratch, uint32_t pc, uint32_t P);
+void launch_solve(hipStream_t st, DevCircuit dc, Fr* W, Fr* scratch, uint32_t pc_begin, uint32_t pc_end, uint32_t P);
+// wide forms of the two data-parallel solver instructions (one lane per (element chunk, proof) instead of one per proof)
+void launch_batch_div(hipStream_t st, DevCircuit dc, Fr* W, Fr* scratch, uint32_t k0, uint32_t n, uint32_t P);
+void launch_count8(hipStream_t st, DevCircuit dc, Fr* W, uint32_t* counters, uint32_t h0, uint32_t n, uint32_t out0, uint32_t P);
 // a,b,c evaluation + satisfaction check (status[p] |= 1 when some row fails)
 void launch_spmv_check(hipStream_t st, DevCircuit dc, const Fr* W, Fr* abc, uint32_t n, uint32_t P, uint32_t* status);
 

@@ -218,11 +218,12 @@ __device__ __noinline__ void dev_grumpkin(const DevCircuit& dc, Fr* __restrict__
   }
 }
 
-__global__ void __launch_bounds__(64) k_solve(DevCircuit dc, Fr* __restrict__ W, Fr* __restrict__ scratch, uint32_t pc, uint32_t P) {
+__global__ void __launch_bounds__(64) k_solve(DevCircuit dc, Fr* __restrict__ W, Fr* __restrict__ scratch, uint32_t pc, uint32_t pc_end,
+                                              uint32_t P) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
   const uint32_t* __restrict__ pr = dc.program;
-  for (;;) {
+  while (pc < pc_end) {
     const uint32_t op = pr[pc];
     if (op == OP_END || op == OP_COMMIT) break;
     switch (op) {
@@ -277,7 +278,7 @@ __global__ void __launch_bounds__(64) k_solve(DevCircuit dc, Fr* __restrict__ W,
             const uint32_t li = i >> 2;
             word = li == 0 ? c[0] : li == 1 ? c[1] : li == 2 ? c[2] : li == 3 ? c[3] : li == 4 ? c[4] : li == 5 ? c[5] : li == 6 ? c[6] : c[7];
           }
-          W[(size_t)(out0 + i) * P + p] = Fr::from_u64(word & 0xFF);
+          W[(size_t)(out0 + i) * P + p] = dc.byte_mont[word & 0xFF];
           word >>= 8;
         }
         break;
@@ -331,8 +332,54 @@ __global__ void __launch_bounds__(64) k_solve(DevCircuit dc, Fr* __restrict__ W,
     }
   }
 }
-void launch_solve(hipStream_t st, DevCircuit dc, Fr* W, Fr* scratch, uint32_t pc, uint32_t P) {
-  hipLaunchKernelGGL(k_solve, dim3((P + 63) / 64), dim3(64), 0, st, dc, W, scratch, pc, P);
+void launch_solve(hipStream_t st, DevCircuit dc, Fr* W, Fr* scratch, uint32_t pc_begin, uint32_t pc_end, uint32_t P) {
+  if (pc_begin >= pc_end) return;
+  hipLaunchKernelGGL(k_solve, dim3((P + 63) / 64), dim3(64), 0, st, dc, W, scratch, pc_begin, pc_end, P);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// wide OP_BATCH_DIV: lane -> (chunk of DIV_CHUNK consecutive constraints, proof); one inversion per chunk
+// ---------------------------------------------------------------------------------------------------
+static constexpr uint32_t DIV_CHUNK = 32;
+__global__ void __launch_bounds__(64) k_batch_div(DevCircuit dc, Fr* __restrict__ W, Fr* __restrict__ scratch, uint32_t k0, uint32_t n,
+                                                  uint32_t P) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t nchunks = (n + DIV_CHUNK - 1) / DIV_CHUNK;
+  if (g >= (uint64_t)nchunks * P) return;
+  const uint32_t p = (uint32_t)(g % P), chunk = (uint32_t)(g / P);
+  const uint32_t i0 = chunk * DIV_CHUNK;
+  const uint32_t cnt = n - i0 < DIV_CHUNK ? n - i0 : DIV_CHUNK;
+  dev_div_range(dc, W, scratch + (size_t)i0 * P, k0 + i0, cnt, P, p);
+}
+void launch_batch_div(hipStream_t st, DevCircuit dc, Fr* W, Fr* scratch, uint32_t k0, uint32_t n, uint32_t P) {
+  if (n == 0) return;
+  uint64_t lanes = (uint64_t)((n + DIV_CHUNK - 1) / DIV_CHUNK) * P;
+  hipLaunchKernelGGL(k_batch_div, dim3((uint32_t)((lanes + 63) / 64)), dim3(64), 0, st, dc, W, scratch, k0, n, P);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// wide OP_COUNT8: histogram of n looked-up values per proof with integer atomics, then conversion to Fr
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_count8_hist(DevCircuit dc, const Fr* __restrict__ W, uint32_t* __restrict__ counters, uint32_t h0,
+                                                     uint32_t n, uint32_t P) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (uint64_t)n * P) return;
+  const uint32_t p = (uint32_t)(g % P), i = (uint32_t)(g / P);
+  Fr v = dev_row_dot(dc.H, dc.coeffs, h0 + i, 0, W, P, p);
+  uint32_t c[8];
+  v.to_canonical(c);
+  if (c[0] < 256 && (c[1] | c[2] | c[3] | c[4] | c[5] | c[6] | c[7]) == 0) atomicAdd(&counters[(size_t)c[0] * P + p], 1u);
+}
+__global__ void __launch_bounds__(256) k_count8_store(const uint32_t* __restrict__ counters, Fr* __restrict__ W, uint32_t out0, uint32_t P) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= 256 * P) return;
+  W[(size_t)out0 * P + g] = Fr::from_u64(counters[g]);
+}
+void launch_count8(hipStream_t st, DevCircuit dc, Fr* W, uint32_t* counters, uint32_t h0, uint32_t n, uint32_t out0, uint32_t P) {
+  (void)hipMemsetAsync(counters, 0, sizeof(uint32_t) * 256 * (size_t)P, st);
+  uint64_t lanes = (uint64_t)n * P;
+  if (lanes) hipLaunchKernelGGL(k_count8_hist, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, st, dc, W, counters, h0, n, P);
+  hipLaunchKernelGGL(k_count8_store, dim3((256 * P + 255) / 256), dim3(256), 0, st, counters, W, out0, P);
 }
 
 // ---------------------------------------------------------------------------------------------------

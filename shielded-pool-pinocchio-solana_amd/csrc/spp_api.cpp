@@ -155,6 +155,7 @@ struct Workspace {
   G1Affine* commit_affine = nullptr;
   uint8_t *d_inputs = nullptr, *d_rs = nullptr, *d_proofs = nullptr, *d_pws = nullptr;
   uint32_t* d_status = nullptr;
+  uint32_t* counters = nullptr;   // [256][P] lookup histogram
   MsmBuf<Fq> A, B1, K, Z, CB, CS;
   MsmBuf<Fq2> B2;
   std::vector<void*> owned;
@@ -163,12 +164,17 @@ struct Workspace {
   size_t msm_ev_used = 0;
 };
 
+struct SolveStep {
+  enum Kind { SEQ, BATCH_DIV, COUNT8, COMMIT } kind;
+  uint32_t a = 0, b = 0, c = 0;   // SEQ: [pc_begin, pc_end) ; BATCH_DIV: k0, n ; COUNT8: h0, n, out0
+};
 struct spp_circuit {
   spp_ctx* ctx = nullptr;
+  std::vector<SolveStep> schedule;
   Circuit circ;
   DevCircuit dc{};
   uint32_t c_bits = 10, n = 0, logn = 0;
-  uint32_t pc_phase2 = 0, max_batch_div = SOLVE_SCRATCH_MIN_ROWS;
+  uint32_t max_batch_div = SOLVE_SCRATCH_MIN_ROWS;
   uint32_t row_r = 0, row_s = 0, row_rs = 0, n_rows = 0;
   uint64_t table_bytes = 0;
   MsmSet<Fq> A, B1, K, Z, CB, CS;
@@ -440,24 +446,52 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
     if ((e = own_upload(c, &a, p3.rc)) || (e = own_upload(c, &b, flat(p3))) || (e = own_upload(c, &cc, p5.rc)) ||
         (e = own_upload(c, &d, flat(p5))) || (e = own_upload(c, &f, p2.rc)) || (e = own_upload(c, &g, mu)))
       return e;
+    std::vector<Fr> bytes(256);
+    for (int i = 0; i < 256; i++) bytes[i] = Fr::from_u64((uint64_t)i);
+    Fr* bm;
+    if ((e = own_upload(c, &bm, bytes))) return e;
+    c->dc.byte_mont = bm;
     c->dc.pos3_rc = a; c->dc.pos3_mds = b; c->dc.pos5_rc = cc; c->dc.pos5_mds = d; c->dc.p2_rc = f; c->dc.p2_mu = g;
   }
-  // program scan: phase-2 entry and largest batch division
+  // program scan: split into sequential segments (one lane per proof) and wide steps (data-parallel instructions
+  // that get their own kernels: batch divisions and lookup histograms), with the commitment boundary in between
   {
     const auto& pr = circ.program;
-    size_t pc = 0;
-    c->pc_phase2 = 0;
+    size_t pc = 0, seg = 0;
+    auto flush = [&](size_t end) {
+      if (end > seg) c->schedule.push_back({SolveStep::SEQ, (uint32_t)seg, (uint32_t)end, 0});
+    };
     while (pc < pr.size() && pr[pc] != OP_END) {
       switch (pr[pc]) {
         case OP_SOLVE_C: case OP_SOLVE_A: pc += 2; break;
-        case OP_BATCH_DIV: c->max_batch_div = std::max(c->max_batch_div, pr[pc + 2]); pc += 3; break;
-        case OP_BITS: case OP_LIMBS8: case OP_COUNT8: case OP_POSEIDON: pc += 4; break;
+        case OP_BATCH_DIV:
+          c->max_batch_div = std::max(c->max_batch_div, pr[pc + 2]);
+          if (pr[pc + 2] >= 64) {
+            flush(pc);
+            c->schedule.push_back({SolveStep::BATCH_DIV, pr[pc + 1], pr[pc + 2], 0});
+            seg = pc + 3;
+          }
+          pc += 3;
+          break;
+        case OP_COUNT8:
+          flush(pc);
+          c->schedule.push_back({SolveStep::COUNT8, pr[pc + 1], pr[pc + 2], pr[pc + 3]});
+          seg = pc + 4;
+          pc += 4;
+          break;
+        case OP_BITS: case OP_LIMBS8: case OP_POSEIDON: pc += 4; break;
         case OP_POSEIDON2: pc += 3; break;
-        case OP_COMMIT: pc += 1; c->pc_phase2 = (uint32_t)pc; break;
+        case OP_COMMIT:
+          flush(pc);
+          c->schedule.push_back({SolveStep::COMMIT, 0, 0, 0});
+          pc += 1;
+          seg = pc;
+          break;
         case OP_GRUMPKIN: pc += 5 + pr[pc + 4]; break;
         default: return fail(SPP_ERR_FORMAT, "bad opcode %u in solver program", pr[pc]);
       }
     }
+    flush(pc);
   }
 
   // ---- NTT tables ----
@@ -608,7 +642,7 @@ static int ensure_workspace(spp_circuit* c, Workspace& w, size_t P) {
       (e = ws_alloc(w, &w.scratch, (size_t)c->max_batch_div * P)) || (e = ws_alloc(w, &w.commit_affine, P)) ||
       (e = ws_alloc(w, &w.d_inputs, (size_t)c->circ.n_inputs() * 32 * P)) || (e = ws_alloc(w, &w.d_rs, 64 * P)) ||
       (e = ws_alloc(w, &w.d_proofs, (size_t)SPP_PROOF_LEN * P)) || (e = ws_alloc(w, &w.d_pws, (12 + 32 * npub) * P)) ||
-      (e = ws_alloc(w, &w.d_status, P)))
+      (e = ws_alloc(w, &w.d_status, P)) || (e = ws_alloc(w, &w.counters, 256 * P)))
     return e;
   if ((e = ws_set(w, &c->A, &w.A, P)) || (e = ws_set(w, &c->B1, &w.B1, P)) || (e = ws_set(w, &c->B2, &w.B2, P)) ||
       (e = ws_set(w, &c->K, &w.K, P)) || (e = ws_set(w, &c->Z, &w.Z, P)) || (e = ws_set(w, &c->CB, &w.CB, P)) ||
@@ -643,10 +677,17 @@ static int prove_on_device(spp_circuit* c, Workspace& w, uint32_t P, const uint8
   hipEventRecord(w.ev[0], st);
   // 1. inputs, solver phase 1, commitment, challenge, solver phase 2
   launch_load_inputs(st, d_inputs, d_rs, w.W, circ.n_inputs(), circ.n_wires, P);
-  launch_solve(st, c->dc, w.W, w.scratch, 0, P);
-  run_msm(c, w, c->CB, w.CB, P, true);
-  launch_challenge(st, w.CB.out, w.W, circ.challenge_wire, P, w.commit_affine, d_status);
-  launch_solve(st, c->dc, w.W, w.scratch, c->pc_phase2, P);
+  for (const SolveStep& s : c->schedule) {
+    switch (s.kind) {
+      case SolveStep::SEQ: launch_solve(st, c->dc, w.W, w.scratch, s.a, s.b, P); break;
+      case SolveStep::BATCH_DIV: launch_batch_div(st, c->dc, w.W, w.scratch, s.a, s.b, P); break;
+      case SolveStep::COUNT8: launch_count8(st, c->dc, w.W, w.counters, s.a, s.b, s.c, P); break;
+      case SolveStep::COMMIT:
+        run_msm(c, w, c->CB, w.CB, P, true);
+        launch_challenge(st, w.CB.out, w.W, circ.challenge_wire, P, w.commit_affine, d_status);
+        break;
+    }
+  }
   hipEventRecord(w.ev[1], st);
   // 2. constraint evaluations + satisfaction check
   launch_spmv_check(st, c->dc, w.W, w.abc, n, P, d_status);
