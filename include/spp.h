@@ -113,6 +113,34 @@ int spp_prove_withdraw(spp_circuit* c, const spp_withdraw_inputs* in, const uint
 /* debug / parity: full witness of proof 0 of the last batch, n_wires * 32 B big-endian */
 int spp_debug_witness(spp_circuit* c, uint8_t* out, size_t n_wires);
 
+/* ---- witness-input generation (what the reference computes on the client before proving) ---- */
+/* RLWE encryption + quotient witnesses for `count` instances (scripts/generate_audit.py:507-554, rlwe.ts:157-247):
+ * pk_a, pk_b: 1024 coefficients in [0,q); r, e2: count*1024 int8; e1: count*64 int8; msg: count*64 bytes.
+ * Out: c0 count*64, c1 count*1024 (in [0,q)); k0 count*64, k1 count*1024 (signed quotients);
+ * packed_be (optional): count * 157 fields of 32 B big-endian = pack_values(c0) ++ pack_values(c1) (:154-163). */
+int spp_rlwe_witness_batch(spp_ctx* ctx, const uint32_t* pk_a, const uint32_t* pk_b, size_t count, const int8_t* r, const int8_t* e1,
+                           const int8_t* e2, const uint8_t* msg, uint32_t* c0, uint32_t* c1, int32_t* k0, int32_t* k1,
+                           uint8_t* packed_be);
+/* same, every pointer a device pointer; asynchronous on the context stream until spp_ctx_sync() */
+int spp_rlwe_witness_batch_device(spp_ctx* ctx, const void* d_pk_a, const void* d_pk_b, size_t count, const void* d_r, const void* d_e1,
+                                  const void* d_e2, const void* d_msg, void* d_c0, void* d_c1, void* d_k0, void* d_k1,
+                                  void* d_packed_be);
+int spp_ctx_sync(spp_ctx* ctx);
+/* Poseidon hash_2 / hash_4 (client/merkle.ts:22-38): in = count * arity * 32 B, out = count * 32 B */
+int spp_poseidon_hash_batch(spp_ctx* ctx, size_t count, int arity, const uint8_t* in, uint8_t* out);
+/* compute_merkle_root (noir_circuit/src/main.nr:11-29) for count paths: siblings = count * depth * 32 B */
+int spp_merkle_root_batch(spp_ctx* ctx, size_t count, uint32_t depth, const uint8_t* leaves, const uint64_t* indices,
+                          const uint8_t* siblings, uint8_t* roots);
+/* ShieldedPoolMerkleTree.getRoot + getProof (client/merkle.ts:165-221): tree of n_leaves inserted leaves, missing
+ * nodes = default hashes (:150-156); siblings_out = n_queries * depth * 32 B */
+int spp_merkle_build(spp_ctx* ctx, size_t n_leaves, uint32_t depth, const uint8_t* leaves, size_t n_queries,
+                     const uint64_t* query_indices, uint8_t* siblings_out, uint8_t* root_out);
+/* generateIdentityKeypair's sk * G on Grumpkin (client/merkle.ts:98-113; scalar = the canonical field element,
+ * as noir_circuit/src/main.nr:54-59): sk count * 32 B -> (x, y) count * 64 B */
+int spp_grumpkin_keygen_batch(spp_ctx* ctx, size_t count, const uint8_t* sk, uint8_t* xy);
+/* ct_commitment sponge (ct_helper/src/main.nr:15-34): in = count * n * 32 B, out = count * 32 B */
+int spp_poseidon2_sponge_batch(spp_ctx* ctx, size_t count, uint32_t n, const uint8_t* in, uint8_t* out);
+
 /* ---- micro-benchmark / unit entry points ---- */
 /* data: n = 2^logn elements, 32 B big-endian each, natural order in and out */
 int spp_ntt_fr(spp_ctx* ctx, uint8_t* data, uint32_t logn, int inverse);

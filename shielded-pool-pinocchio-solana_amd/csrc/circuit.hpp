@@ -312,6 +312,8 @@ void gadget_poseidon2_permute(Builder& b, LC state[4], bool native_hint);
 // Grumpkin fixed-base multiplication by the 254 little-endian bits of the scalar; returns (x, y)
 std::pair<LC, LC> gadget_grumpkin_fixed_base(Builder& b, const std::vector<LC>& bits, bool native_hint);
 
+GkAffine grumpkin_generator();
+GkAffine grumpkin_offset();
 Circuit build_withdraw_circuit(bool native_hints);
 Circuit build_audit_circuit(const uint32_t* pk_a, const uint32_t* pk_b, bool native_hints);
 

@@ -35,6 +35,25 @@ struct DevCircuit {
   const Fr* byte_mont;                      // Montgomery forms of 0..255
 };
 
+// Poseidon / Poseidon2 constants in HBM (Montgomery form), shared by the solver and the stand-alone hash kernels
+struct HashConsts {
+  const Fr* pos3_rc;  const Fr* pos3_mds;
+  const Fr* pos5_rc;  const Fr* pos5_mds;
+  const Fr* p2_rc;    const Fr* p2_mu;
+};
+
+// ---- stand-alone witness-input kernels (kernels_witness.hip) ----
+void launch_rlwe_witness(hipStream_t st, const uint32_t* pk_a, const uint32_t* pk_b, const int8_t* r, const int8_t* e1, const int8_t* e2,
+                         const uint8_t* msg, uint32_t* c0, uint32_t* c1, int32_t* k0, int32_t* k1, uint8_t* packed_be, uint32_t count);
+void launch_poseidon_hash(hipStream_t st, HashConsts hc, const uint8_t* in_be, uint32_t arity, uint8_t* out_be, uint32_t count);
+void launch_merkle_path(hipStream_t st, HashConsts hc, const uint8_t* leaf_be, const uint64_t* index, const uint8_t* siblings_be,
+                        uint32_t depth, uint8_t* root_be, uint32_t count);
+void launch_merkle_level(hipStream_t st, HashConsts hc, const Fr* children, uint32_t n_children, Fr dflt, Fr* parents, uint32_t n_parents);
+void launch_fr_from_be(hipStream_t st, const uint8_t* in, Fr* out, uint32_t n);
+void launch_fr_to_be(hipStream_t st, const Fr* in, uint8_t* out, uint32_t n);
+void launch_grumpkin_keygen(hipStream_t st, const GkAffine* table, const uint8_t* sk_be, uint8_t* xy_be, uint32_t count);
+void launch_poseidon2_sponge(hipStream_t st, HashConsts hc, const uint8_t* in_be, uint32_t n, uint8_t* out_be, uint32_t count);
+
 // ---- witness ----
 void launch_load_inputs(hipStream_t st, const uint8_t* d_inputs_be, const uint8_t* d_rs_be, Fr* W, uint32_t n_inputs,
                         uint32_t n_wires, uint32_t P);

@@ -1,3 +1,313 @@
-// Stand-alone witness-input kernels (RLWE negacyclic, Poseidon-Merkle, Grumpkin keygen) -- added below.
+// Stand-alone witness-INPUT kernels: everything the reference computes on the client before it can call the
+// prover, batched on the GPU.
+//
+//   k_rlwe_witness        scripts/generate_audit.py:45-66,236-243,507-554 (negacyclic products, quotient witnesses)
+//                         + pack_values :154-163  -- also demo-frontend/app/lib/rlwe.ts:157-247
+//   k_poseidon_hash       client/merkle.ts:22-38 (poseidonHash2/4), noir_circuit/src/main.nr:1-9
+//   k_merkle_path         noir_circuit/src/main.nr:11-29, client/merkle.ts:198-221
+//   k_merkle_level        client/merkle.ts:165-176 (getRoot: one tree level per launch)
+//   k_grumpkin_keygen     client/merkle.ts:98-113 (generateIdentityKeypair), main.nr:54-59
+//   k_poseidon2_sponge    ct_helper/src/main.nr:15-34 (= scripts/generate_audit.py:355-374)
 #include "kernels.hpp"
-namespace spp {}
+
+namespace spp {
+
+// ----------------------------------------------------------------------------------------------------
+// RLWE: one 128-lane workgroup per instance.  The public key rows are negacyclic shifts of a (resp. b), so
+//   <row_i, r> = sum_j A2[(i - j) mod 2048] * r[j],  A2 = [a, (q - a) mod q]   (entries in [0,q), as the
+// reference's negacyclic_matrix_row_mod_q): each lane keeps 8 consecutive outputs in 64-bit accumulators and
+// slides an 8-entry window of A2 through registers, so one LDS read of A2 and one broadcast read of r[j] feed
+// 8 exact integer multiply-adds (v_mad_i64_i32; |sum| < 2^46).  Quotient and remainder by q follow Python's
+// floor semantics (generate_audit.py:241-242).
+// ----------------------------------------------------------------------------------------------------
+static constexpr int RL_N = 1024, RL_SLOTS = 64;
+static constexpr long long RL_Q = 167772161ll, RL_DELTA = 655360ll;
+
+__device__ __forceinline__ void floordiv_q(long long v, long long& k, uint32_t& rem) {
+  long long q = v / RL_Q, r = v % RL_Q;
+  if (r < 0) { r += RL_Q; q -= 1; }
+  k = q;
+  rem = (uint32_t)r;
+}
+
+__global__ void __launch_bounds__(128) k_rlwe_witness(const uint32_t* __restrict__ pk_a, const uint32_t* __restrict__ pk_b,
+                                                      const int8_t* __restrict__ r_in, const int8_t* __restrict__ e1_in,
+                                                      const int8_t* __restrict__ e2_in, const uint8_t* __restrict__ msg_in,
+                                                      uint32_t* __restrict__ c0_out, uint32_t* __restrict__ c1_out,
+                                                      int32_t* __restrict__ k0_out, int32_t* __restrict__ k1_out,
+                                                      uint8_t* __restrict__ packed_be, uint32_t count) {
+  __shared__ int32_t A2[2 * RL_N];
+  __shared__ int32_t B2[2 * RL_N];
+  __shared__ int32_t rs[RL_N];
+  __shared__ uint32_t cs[RL_SLOTS + RL_N];   // c0 then c1, for the packing epilogue
+  const uint32_t inst = blockIdx.x;
+  if (inst >= count) return;
+  const int t = threadIdx.x;
+  for (int i = t; i < RL_N; i += 128) {
+    uint32_t a = pk_a[i], b = pk_b[i];
+    A2[i] = (int32_t)a;
+    A2[RL_N + i] = a ? (int32_t)(RL_Q - a) : 0;
+    B2[i] = (int32_t)b;
+    B2[RL_N + i] = b ? (int32_t)(RL_Q - b) : 0;
+    rs[i] = r_in[(size_t)inst * RL_N + i];
+  }
+  __syncthreads();
+  // ---- c1 / k1: outputs i0 .. i0+7 ----
+  {
+    const int i0 = 8 * t;
+    long long acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) acc[u] = 0;
+    int32_t win[8];   // win[u] = A2[(i0 + u - j) mod 2048]
+#pragma unroll
+    for (int u = 0; u < 8; u++) win[u] = A2[(i0 + u) & 2047];
+    for (int j = 0; j < RL_N; j++) {
+      const int32_t rj = rs[j];
+#pragma unroll
+      for (int u = 0; u < 8; u++) acc[u] += (long long)win[u] * rj;
+      // slide: next j needs A2[i0 + u - (j+1)] = previous win[u-1]; new head A2[i0 - (j+1)]
+#pragma unroll
+      for (int u = 7; u > 0; u--) win[u] = win[u - 1];
+      win[0] = A2[(i0 - (j + 1)) & 2047];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int i = i0 + u;
+      long long k;
+      uint32_t rem;
+      floordiv_q(acc[u] + (long long)e2_in[(size_t)inst * RL_N + i], k, rem);
+      c1_out[(size_t)inst * RL_N + i] = rem;
+      k1_out[(size_t)inst * RL_N + i] = (int32_t)k;
+      cs[RL_SLOTS + i] = rem;
+    }
+  }
+  // ---- c0 / k0: 64 outputs, one per lane of the first wave ----
+  if (t < RL_SLOTS) {
+    long long acc = 0;
+    for (int j = 0; j < RL_N; j++) acc += (long long)B2[(t - j) & 2047] * rs[j];
+    long long k;
+    uint32_t rem;
+    floordiv_q(acc + (long long)e1_in[(size_t)inst * RL_SLOTS + t] + RL_DELTA * (long long)msg_in[(size_t)inst * RL_SLOTS + t], k, rem);
+    c0_out[(size_t)inst * RL_SLOTS + t] = rem;
+    k0_out[(size_t)inst * RL_SLOTS + t] = (int32_t)k;
+    cs[t] = rem;
+  }
+  __syncthreads();
+  // ---- pack 7 x 32-bit per field (pack_values), 32-byte big-endian: 10 + 147 fields ----
+  if (packed_be) {
+    uint8_t* out = packed_be + (size_t)inst * 157 * 32;
+    for (int w = t; w < 157 * 8; w += 128) {
+      const int f = w / 8, jw = w % 8;            // jw-th little-endian 32-bit word of field f
+      uint32_t v = 0;
+      if (jw < 7) {
+        if (f < 10) { int idx = 7 * f + jw; if (idx < RL_SLOTS) v = cs[idx]; }
+        else { int idx = 7 * (f - 10) + jw; if (idx < RL_N) v = cs[RL_SLOTS + idx]; }
+      }
+      uint8_t* o = out + f * 32 + (28 - 4 * jw);
+      o[0] = (uint8_t)(v >> 24); o[1] = (uint8_t)(v >> 16); o[2] = (uint8_t)(v >> 8); o[3] = (uint8_t)v;
+    }
+  }
+}
+void launch_rlwe_witness(hipStream_t st, const uint32_t* pk_a, const uint32_t* pk_b, const int8_t* r, const int8_t* e1, const int8_t* e2,
+                         const uint8_t* msg, uint32_t* c0, uint32_t* c1, int32_t* k0, int32_t* k1, uint8_t* packed_be, uint32_t count) {
+  if (count == 0) return;
+  hipLaunchKernelGGL(k_rlwe_witness, dim3(count), dim3(128), 0, st, pk_a, pk_b, r, e1, e2, msg, c0, c1, k0, k1, packed_be, count);
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Poseidon (t = 3, 5), permutation with the state in registers; one lane per hash
+// ----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ Fr load_be(const uint8_t* p) {
+  uint8_t buf[32];
+  for (int i = 0; i < 32; i++) buf[i] = p[i];
+  return Fr::from_bytes_be(buf);
+}
+__device__ __forceinline__ void store_be(uint8_t* p, const Fr& v) {
+  uint8_t buf[32];
+  v.to_bytes_be(buf);
+  for (int i = 0; i < 32; i++) p[i] = buf[i];
+}
+__device__ __forceinline__ Fr sbox5(const Fr& x) {
+  Fr x2 = x.sqr();
+  return x2.sqr() * x;
+}
+template <int T>
+__device__ __noinline__ void poseidon_permute(Fr (&s)[T], const Fr* __restrict__ rc, const Fr* __restrict__ mds, int rp) {
+  const int rf = 8;
+#pragma unroll 1
+  for (int r = 0; r < rf + rp; r++) {
+    SPP_UNROLL for (int i = 0; i < T; i++) s[i] = s[i] + rc[r * T + i];
+    if (r < rf / 2 || r >= rf / 2 + rp) {
+      SPP_UNROLL for (int i = 0; i < T; i++) s[i] = sbox5(s[i]);
+    } else {
+      s[0] = sbox5(s[0]);
+    }
+    Fr nx[T];
+    SPP_UNROLL for (int i = 0; i < T; i++) {
+      nx[i] = mds[i * T] * s[0];
+      SPP_UNROLL for (int j = 1; j < T; j++) nx[i] = nx[i] + mds[i * T + j] * s[j];
+    }
+    SPP_UNROLL for (int i = 0; i < T; i++) s[i] = nx[i];
+  }
+}
+__device__ __forceinline__ Fr poseidon_hash2(const HashConsts& hc, const Fr& a, const Fr& b) {
+  Fr s[3] = {Fr::zero(), a, b};
+  poseidon_permute<3>(s, hc.pos3_rc, hc.pos3_mds, 57);
+  return s[0];
+}
+
+__global__ void __launch_bounds__(64) k_poseidon_hash(HashConsts hc, const uint8_t* __restrict__ in_be, uint32_t arity,
+                                                      uint8_t* __restrict__ out_be, uint32_t count) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= count) return;
+  const uint8_t* in = in_be + (size_t)g * arity * 32;
+  Fr h;
+  if (arity == 2) {
+    h = poseidon_hash2(hc, load_be(in), load_be(in + 32));
+  } else {
+    Fr s[5] = {Fr::zero(), load_be(in), load_be(in + 32), load_be(in + 64), load_be(in + 96)};
+    poseidon_permute<5>(s, hc.pos5_rc, hc.pos5_mds, 60);
+    h = s[0];
+  }
+  store_be(out_be + (size_t)g * 32, h);
+}
+void launch_poseidon_hash(hipStream_t st, HashConsts hc, const uint8_t* in_be, uint32_t arity, uint8_t* out_be, uint32_t count) {
+  if (count) hipLaunchKernelGGL(k_poseidon_hash, dim3((count + 63) / 64), dim3(64), 0, st, hc, in_be, arity, out_be, count);
+}
+
+// root of one authentication path per lane (main.nr:11-29)
+__global__ void __launch_bounds__(64) k_merkle_path(HashConsts hc, const uint8_t* __restrict__ leaf_be, const uint64_t* __restrict__ index,
+                                                    const uint8_t* __restrict__ siblings_be, uint32_t depth, uint8_t* __restrict__ root_be,
+                                                    uint32_t count) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= count) return;
+  Fr cur = load_be(leaf_be + (size_t)g * 32);
+  const uint64_t idx = index[g];
+  for (uint32_t i = 0; i < depth; i++) {
+    Fr sib = load_be(siblings_be + ((size_t)g * depth + i) * 32);
+    cur = ((idx >> i) & 1) ? poseidon_hash2(hc, sib, cur) : poseidon_hash2(hc, cur, sib);
+  }
+  store_be(root_be + (size_t)g * 32, cur);
+}
+void launch_merkle_path(hipStream_t st, HashConsts hc, const uint8_t* leaf_be, const uint64_t* index, const uint8_t* siblings_be,
+                        uint32_t depth, uint8_t* root_be, uint32_t count) {
+  if (count) hipLaunchKernelGGL(k_merkle_path, dim3((count + 63) / 64), dim3(64), 0, st, hc, leaf_be, index, siblings_be, depth, root_be, count);
+}
+
+// one tree level: parents[j] = H(children[2j], children[2j+1]); a missing right/left child is the level's default hash
+__global__ void __launch_bounds__(64) k_merkle_level(HashConsts hc, const Fr* __restrict__ children, uint32_t n_children, Fr dflt,
+                                                     Fr* __restrict__ parents, uint32_t n_parents) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_parents) return;
+  Fr l = 2 * g < n_children ? children[2 * g] : dflt;
+  Fr r = 2 * g + 1 < n_children ? children[2 * g + 1] : dflt;
+  parents[g] = poseidon_hash2(hc, l, r);
+}
+void launch_merkle_level(hipStream_t st, HashConsts hc, const Fr* children, uint32_t n_children, Fr dflt, Fr* parents, uint32_t n_parents) {
+  if (n_parents) hipLaunchKernelGGL(k_merkle_level, dim3((n_parents + 63) / 64), dim3(64), 0, st, hc, children, n_children, dflt, parents, n_parents);
+}
+__global__ void __launch_bounds__(256) k_fr_from_be(const uint8_t* __restrict__ in, Fr* __restrict__ out, uint32_t n) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < n) out[g] = load_be(in + (size_t)g * 32);
+}
+__global__ void __launch_bounds__(256) k_fr_to_be(const Fr* __restrict__ in, uint8_t* __restrict__ out, uint32_t n) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < n) store_be(out + (size_t)g * 32, in[g]);
+}
+void launch_fr_from_be(hipStream_t st, const uint8_t* in, Fr* out, uint32_t n) {
+  if (n) hipLaunchKernelGGL(k_fr_from_be, dim3((n + 255) / 256), dim3(256), 0, st, in, out, n);
+}
+void launch_fr_to_be(hipStream_t st, const Fr* in, uint8_t* out, uint32_t n) {
+  if (n) hipLaunchKernelGGL(k_fr_to_be, dim3((n + 255) / 256), dim3(256), 0, st, in, out, n);
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Grumpkin key generation: pk = sk * G with a 4-bit window table T[j][d] = (d+1) * 16^j * G (64 x 15 used)
+// ----------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_grumpkin_keygen(const GkAffine* __restrict__ table, const uint8_t* __restrict__ sk_be,
+                                                        uint8_t* __restrict__ xy_be, uint32_t count) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= count) return;
+  Fr sk = load_be(sk_be + (size_t)g * 32);
+  uint32_t c[8];
+  sk.to_canonical(c);
+  GkXYZZ acc = GkXYZZ::infinity();
+  uint32_t word = 0;
+#pragma unroll 1
+  for (uint32_t j = 0; j < 64; j++) {
+    if ((j & 7) == 0) {
+      const uint32_t li = j >> 3;
+      word = li == 0 ? c[0] : li == 1 ? c[1] : li == 2 ? c[2] : li == 3 ? c[3] : li == 4 ? c[4] : li == 5 ? c[5] : li == 6 ? c[6] : c[7];
+    }
+    const uint32_t d = word & 15;
+    word >>= 4;
+    if (d) acc.madd(table[j * 16 + d - 1]);
+  }
+  GkAffine p = acc.to_affine();
+  store_be(xy_be + (size_t)g * 64, p.x);
+  store_be(xy_be + (size_t)g * 64 + 32, p.y);
+}
+void launch_grumpkin_keygen(hipStream_t st, const GkAffine* table, const uint8_t* sk_be, uint8_t* xy_be, uint32_t count) {
+  if (count) hipLaunchKernelGGL(k_grumpkin_keygen, dim3((count + 63) / 64), dim3(64), 0, st, table, sk_be, xy_be, count);
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Poseidon2 t=4 sponge (rate 3) over n field elements per instance; one lane per instance
+// ----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void p2_external(Fr (&s)[4]) {
+  Fr t01 = s[0] + s[1], t23 = s[2] + s[3];
+  Fr d1 = s[1].dbl(), d3 = s[3].dbl();
+  Fr q0 = s[0].dbl().dbl(), q1 = d1.dbl(), q2 = s[2].dbl().dbl(), q3 = d3.dbl();
+  Fr n0 = q0 + s[0] + q1 + d1 + s[1] + s[2] + d3 + s[3];
+  Fr n1 = q0 + q1 + d1 + t23;
+  Fr n2 = s[0] + d1 + s[1] + q2 + s[2] + q3 + d3 + s[3];
+  Fr n3 = t01 + q2 + q3 + d3;
+  s[0] = n0; s[1] = n1; s[2] = n2; s[3] = n3;
+}
+__device__ __noinline__ void poseidon2_permute(Fr (&s)[4], const Fr* __restrict__ rc, const Fr* __restrict__ mu) {
+  p2_external(s);
+  int k = 0;
+#pragma unroll 1
+  for (int r = 0; r < 4; r++) {
+    SPP_UNROLL for (int i = 0; i < 4; i++) s[i] = sbox5(s[i] + rc[k + i]);
+    k += 4;
+    p2_external(s);
+  }
+#pragma unroll 1
+  for (int r = 0; r < 56; r++) {
+    s[0] = sbox5(s[0] + rc[k]);
+    k++;
+    Fr tot = s[0] + s[1] + s[2] + s[3];
+    SPP_UNROLL for (int i = 0; i < 4; i++) s[i] = mu[i] * s[i] + tot;
+  }
+#pragma unroll 1
+  for (int r = 0; r < 4; r++) {
+    SPP_UNROLL for (int i = 0; i < 4; i++) s[i] = sbox5(s[i] + rc[k + i]);
+    k += 4;
+    p2_external(s);
+  }
+}
+__global__ void __launch_bounds__(64) k_poseidon2_sponge(HashConsts hc, const uint8_t* __restrict__ in_be, uint32_t n,
+                                                         uint8_t* __restrict__ out_be, uint32_t count) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= count) return;
+  const uint8_t* in = in_be + (size_t)g * n * 32;
+  Fr s[4] = {Fr::zero(), Fr::zero(), Fr::zero(), Fr::zero()};
+  const uint32_t full = n / 3;
+  for (uint32_t i = 0; i < full; i++) {
+    s[0] = s[0] + load_be(in + (size_t)(3 * i) * 32);
+    s[1] = s[1] + load_be(in + (size_t)(3 * i + 1) * 32);
+    s[2] = s[2] + load_be(in + (size_t)(3 * i + 2) * 32);
+    poseidon2_permute(s, hc.p2_rc, hc.p2_mu);
+  }
+  const uint32_t rem = n - 3 * full;
+  if (rem >= 1) s[0] = s[0] + load_be(in + (size_t)(3 * full) * 32);
+  if (rem >= 2) s[1] = s[1] + load_be(in + (size_t)(3 * full + 1) * 32);
+  poseidon2_permute(s, hc.p2_rc, hc.p2_mu);
+  store_be(out_be + (size_t)g * 32, s[0]);
+}
+void launch_poseidon2_sponge(hipStream_t st, HashConsts hc, const uint8_t* in_be, uint32_t n, uint8_t* out_be, uint32_t count) {
+  if (count) hipLaunchKernelGGL(k_poseidon2_sponge, dim3((count + 63) / 64), dim3(64), 0, st, hc, in_be, n, out_be, count);
+}
+
+}  // namespace spp

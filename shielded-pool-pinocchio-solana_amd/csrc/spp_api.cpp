@@ -133,6 +133,11 @@ struct spp_ctx {
   hipStream_t pstream[2];    // proving: consecutive batches alternate, so the (latency-bound, few-wave) witness
                              // solver of batch k+1 overlaps the MSMs of batch k
   std::mutex mu;
+  // lazily created constants of the stand-alone witness kernels
+  bool consts_ready = false;
+  HashConsts hc{};
+  GkAffine* gk_table = nullptr;
+  std::vector<void*> owned;
 };
 
 template <class F>
@@ -300,6 +305,7 @@ extern "C" void spp_free_ctx(spp_ctx* ctx) {
   hipStreamDestroy(ctx->stream);
   hipStreamDestroy(ctx->pstream[0]);
   hipStreamDestroy(ctx->pstream[1]);
+  for (void* p : ctx->owned) hipFree(p);
   delete ctx;
 }
 
@@ -1108,5 +1114,231 @@ extern "C" int spp_msm_g1(spp_ctx* ctx, const uint8_t* bases, const uint8_t* sca
   if (d_out) hipFree(d_out);
   if (e) return e;
   g1_to_raw(res.to_affine(), out);
+  return SPP_OK;
+}
+
+// -----------------------------------------------------------------------------------------------------
+// stand-alone witness-input kernels
+// -----------------------------------------------------------------------------------------------------
+template <class T>
+static int ctx_upload(spp_ctx* ctx, T** dst, const std::vector<T>& src) {
+  HIP_TRY(dev_upload(dst, src));
+  ctx->owned.push_back((void*)*dst);
+  return 0;
+}
+static int ensure_ctx_consts(spp_ctx* ctx) {
+  if (ctx->consts_ready) return 0;
+  auto flat = [](const PoseidonParams& pp) {
+    std::vector<Fr> m;
+    for (auto& row : pp.mds)
+      for (auto& v : row) m.push_back(v);
+    return m;
+  };
+  const PoseidonParams& p3 = poseidon_params(3);
+  const PoseidonParams& p5 = poseidon_params(5);
+  const Poseidon2Params& p2 = poseidon2_params();
+  std::vector<Fr> mu(p2.mu, p2.mu + 4);
+  Fr *a, *b, *c, *d, *f, *g;
+  int e;
+  if ((e = ctx_upload(ctx, &a, p3.rc)) || (e = ctx_upload(ctx, &b, flat(p3))) || (e = ctx_upload(ctx, &c, p5.rc)) ||
+      (e = ctx_upload(ctx, &d, flat(p5))) || (e = ctx_upload(ctx, &f, p2.rc)) || (e = ctx_upload(ctx, &g, mu)))
+    return e;
+  ctx->hc = HashConsts{a, b, c, d, f, g};
+  // Grumpkin window table T[j][d] = (d+1) * 16^j * G, j < 64, d < 16
+  std::vector<GkAffine> tab(64 * 16);
+  GkXYZZ base = GkXYZZ::from_affine(grumpkin_generator());
+  for (int j = 0; j < 64; j++) {
+    GkAffine ba = base.to_affine();
+    GkXYZZ run = base;
+    for (int dd = 0; dd < 16; dd++) {
+      tab[j * 16 + dd] = run.to_affine();
+      run.madd(ba);
+    }
+    base = GkXYZZ::from_affine(tab[j * 16 + 15]);
+  }
+  if ((e = ctx_upload(ctx, &ctx->gk_table, tab))) return e;
+  ctx->consts_ready = true;
+  return 0;
+}
+
+namespace {
+// RAII device buffer for the host-pointer convenience entry points
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+  template <class T> T* as() { return (T*)p; }
+};
+}  // namespace
+#define UP(buf, src, bytes)                                                              \
+  do {                                                                                    \
+    HIP_TRY(buf.alloc(bytes));                                                            \
+    if (bytes) HIP_TRY(hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, st));      \
+  } while (0)
+
+extern "C" int spp_rlwe_witness_batch(spp_ctx* ctx, const uint32_t* pk_a, const uint32_t* pk_b, size_t count, const int8_t* r,
+                                      const int8_t* e1, const int8_t* e2, const uint8_t* msg, uint32_t* c0, uint32_t* c1, int32_t* k0,
+                                      int32_t* k1, uint8_t* packed_be) {
+  if (!ctx || !pk_a || !pk_b || !r || !e1 || !e2 || !msg || !c0 || !c1 || !k0 || !k1) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  if (count == 0) return SPP_OK;
+  for (int i = 0; i < 1024; i++)
+    if (pk_a[i] >= 167772161u || pk_b[i] >= 167772161u) return fail(SPP_ERR_BAD_INPUT, "public key coefficient not in [0, q)");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  DevBuf da, db, dr, de1, de2, dm, dc0, dc1, dk0, dk1, dp;
+  UP(da, pk_a, 4096); UP(db, pk_b, 4096);
+  UP(dr, r, count * 1024); UP(de1, e1, count * 64); UP(de2, e2, count * 1024); UP(dm, msg, count * 64);
+  HIP_TRY(dc0.alloc(count * 64 * 4)); HIP_TRY(dc1.alloc(count * 1024 * 4)); HIP_TRY(dk0.alloc(count * 64 * 4)); HIP_TRY(dk1.alloc(count * 1024 * 4));
+  if (packed_be) HIP_TRY(dp.alloc(count * 157 * 32));
+  launch_rlwe_witness(st, da.as<uint32_t>(), db.as<uint32_t>(), dr.as<int8_t>(), de1.as<int8_t>(), de2.as<int8_t>(), dm.as<uint8_t>(),
+                      dc0.as<uint32_t>(), dc1.as<uint32_t>(), dk0.as<int32_t>(), dk1.as<int32_t>(), packed_be ? dp.as<uint8_t>() : nullptr,
+                      (uint32_t)count);
+  HIP_TRY(hipMemcpyAsync(c0, dc0.p, count * 64 * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(c1, dc1.p, count * 1024 * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(k0, dk0.p, count * 64 * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(k1, dk1.p, count * 1024 * 4, hipMemcpyDeviceToHost, st));
+  if (packed_be) HIP_TRY(hipMemcpyAsync(packed_be, dp.p, count * 157 * 32, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipGetLastError());
+  return SPP_OK;
+}
+// device-resident form (micro-benchmark: BASELINE.json configs[3]); all pointers are device pointers
+extern "C" int spp_rlwe_witness_batch_device(spp_ctx* ctx, const void* d_pk_a, const void* d_pk_b, size_t count, const void* d_r,
+                                             const void* d_e1, const void* d_e2, const void* d_msg, void* d_c0, void* d_c1, void* d_k0,
+                                             void* d_k1, void* d_packed_be) {
+  if (!ctx) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  launch_rlwe_witness(ctx->stream, (const uint32_t*)d_pk_a, (const uint32_t*)d_pk_b, (const int8_t*)d_r, (const int8_t*)d_e1,
+                      (const int8_t*)d_e2, (const uint8_t*)d_msg, (uint32_t*)d_c0, (uint32_t*)d_c1, (int32_t*)d_k0, (int32_t*)d_k1,
+                      (uint8_t*)d_packed_be, (uint32_t)count);
+  HIP_TRY(hipGetLastError());
+  return SPP_OK;
+}
+extern "C" int spp_ctx_sync(spp_ctx* ctx) {
+  if (!ctx) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return SPP_OK;
+}
+
+extern "C" int spp_poseidon_hash_batch(spp_ctx* ctx, size_t count, int arity, const uint8_t* in, uint8_t* out) {
+  if (!ctx || !in || !out) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  if (arity != 2 && arity != 4) return fail(SPP_ERR_BAD_INPUT, "arity must be 2 or 4");
+  if (count == 0) return SPP_OK;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (int e = ensure_ctx_consts(ctx)) return e;
+  hipStream_t st = ctx->stream;
+  DevBuf di, dout;
+  UP(di, in, count * arity * 32);
+  HIP_TRY(dout.alloc(count * 32));
+  launch_poseidon_hash(st, ctx->hc, di.as<uint8_t>(), (uint32_t)arity, dout.as<uint8_t>(), (uint32_t)count);
+  HIP_TRY(hipMemcpyAsync(out, dout.p, count * 32, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipGetLastError());
+  return SPP_OK;
+}
+
+extern "C" int spp_merkle_root_batch(spp_ctx* ctx, size_t count, uint32_t depth, const uint8_t* leaves, const uint64_t* indices,
+                                     const uint8_t* siblings, uint8_t* roots) {
+  if (!ctx || !leaves || !indices || !siblings || !roots) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  if (depth == 0 || depth > 64) return fail(SPP_ERR_BAD_INPUT, "depth out of range");
+  if (count == 0) return SPP_OK;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (int e = ensure_ctx_consts(ctx)) return e;
+  hipStream_t st = ctx->stream;
+  DevBuf dl, di, ds, dr;
+  UP(dl, leaves, count * 32); UP(di, indices, count * 8); UP(ds, siblings, count * depth * 32);
+  HIP_TRY(dr.alloc(count * 32));
+  launch_merkle_path(st, ctx->hc, dl.as<uint8_t>(), di.as<uint64_t>(), ds.as<uint8_t>(), depth, dr.as<uint8_t>(), (uint32_t)count);
+  HIP_TRY(hipMemcpyAsync(roots, dr.p, count * 32, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipGetLastError());
+  return SPP_OK;
+}
+
+// ShieldedPoolMerkleTree.getRoot + getProof (client/merkle.ts:165-221) for a tree of n_leaves inserted leaves
+extern "C" int spp_merkle_build(spp_ctx* ctx, size_t n_leaves, uint32_t depth, const uint8_t* leaves, size_t n_queries,
+                                const uint64_t* query_indices, uint8_t* siblings_out, uint8_t* root_out) {
+  if (!ctx || !root_out || (n_leaves && !leaves) || (n_queries && (!query_indices || !siblings_out)))
+    return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  if (depth == 0 || depth > 32 || n_leaves > ((size_t)1 << depth)) return fail(SPP_ERR_BAD_INPUT, "bad depth / too many leaves");
+  for (size_t q = 0; q < n_queries; q++)
+    if (query_indices[q] >= ((uint64_t)1 << depth)) return fail(SPP_ERR_BAD_INPUT, "query index out of range");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (int e = ensure_ctx_consts(ctx)) return e;
+  hipStream_t st = ctx->stream;
+  // level sizes
+  std::vector<size_t> cnt(depth + 1), off(depth + 2, 0);
+  cnt[0] = n_leaves;
+  for (uint32_t i = 0; i < depth; i++) cnt[i + 1] = (cnt[i] + 1) / 2;
+  for (uint32_t i = 0; i <= depth; i++) off[i + 1] = off[i] + std::max<size_t>(cnt[i], 1);
+  DevBuf dleaves, dnodes, ddef;
+  UP(dleaves, leaves, n_leaves * 32);
+  HIP_TRY(dnodes.alloc(off[depth + 1] * sizeof(Fr)));
+  HIP_TRY(ddef.alloc((depth + 1) * sizeof(Fr)));
+  Fr* nodes = dnodes.as<Fr>();
+  launch_fr_from_be(st, dleaves.as<uint8_t>(), nodes, (uint32_t)n_leaves);
+  std::vector<Fr> dflt(depth + 1);
+  dflt[0] = Fr::zero();
+  for (uint32_t i = 0; i < depth; i++) {
+    // default hash of the next level: H(d_i, d_i) -- one lane, read back (depth <= 32 round trips at tree-build time)
+    launch_merkle_level(st, ctx->hc, nullptr, 0, dflt[i], ddef.as<Fr>() + i + 1, 1);
+    HIP_TRY(hipMemcpyAsync(&dflt[i + 1], ddef.as<Fr>() + i + 1, sizeof(Fr), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    launch_merkle_level(st, ctx->hc, nodes + off[i], (uint32_t)cnt[i], dflt[i], nodes + off[i + 1], (uint32_t)cnt[i + 1]);
+  }
+  std::vector<Fr> host(off[depth + 1]);
+  HIP_TRY(hipMemcpyAsync(host.data(), nodes, host.size() * sizeof(Fr), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipGetLastError());
+  Fr root = cnt[depth] ? host[off[depth]] : dflt[depth];
+  root.to_bytes_be(root_out);
+  for (size_t q = 0; q < n_queries; q++) {
+    uint64_t idx = query_indices[q];
+    for (uint32_t i = 0; i < depth; i++) {
+      uint64_t sib = idx ^ 1;
+      Fr v = sib < cnt[i] ? host[off[i] + sib] : dflt[i];
+      v.to_bytes_be(siblings_out + (q * depth + i) * 32);
+      idx >>= 1;
+    }
+  }
+  return SPP_OK;
+}
+
+extern "C" int spp_grumpkin_keygen_batch(spp_ctx* ctx, size_t count, const uint8_t* sk, uint8_t* xy) {
+  if (!ctx || !sk || !xy) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  if (count == 0) return SPP_OK;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (int e = ensure_ctx_consts(ctx)) return e;
+  hipStream_t st = ctx->stream;
+  DevBuf ds, dx;
+  UP(ds, sk, count * 32);
+  HIP_TRY(dx.alloc(count * 64));
+  launch_grumpkin_keygen(st, ctx->gk_table, ds.as<uint8_t>(), dx.as<uint8_t>(), (uint32_t)count);
+  HIP_TRY(hipMemcpyAsync(xy, dx.p, count * 64, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipGetLastError());
+  return SPP_OK;
+}
+
+extern "C" int spp_poseidon2_sponge_batch(spp_ctx* ctx, size_t count, uint32_t n, const uint8_t* in, uint8_t* out) {
+  if (!ctx || !in || !out) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  if (count == 0) return SPP_OK;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (int e = ensure_ctx_consts(ctx)) return e;
+  hipStream_t st = ctx->stream;
+  DevBuf di, dout;
+  UP(di, in, count * n * 32);
+  HIP_TRY(dout.alloc(count * 32));
+  launch_poseidon2_sponge(st, ctx->hc, di.as<uint8_t>(), n, dout.as<uint8_t>(), (uint32_t)count);
+  HIP_TRY(hipMemcpyAsync(out, dout.p, count * 32, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipGetLastError());
   return SPP_OK;
 }

@@ -57,6 +57,14 @@ def load_library():
     L.spp_timings.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_float)]
     L.spp_prove_withdraw.argtypes = [vp, ctypes.POINTER(WithdrawInputs), cp, vp, vp]
     L.spp_debug_witness.argtypes = [vp, vp, sz]
+    L.spp_rlwe_witness_batch.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.spp_rlwe_witness_batch_device.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.spp_ctx_sync.argtypes = [vp]
+    L.spp_poseidon_hash_batch.argtypes = [vp, sz, i32, cp, vp]
+    L.spp_merkle_root_batch.argtypes = [vp, sz, u32, cp, vp, cp, vp]
+    L.spp_merkle_build.argtypes = [vp, sz, u32, cp, sz, vp, vp, vp]
+    L.spp_grumpkin_keygen_batch.argtypes = [vp, sz, cp, vp]
+    L.spp_poseidon2_sponge_batch.argtypes = [vp, sz, u32, cp, vp]
     L.spp_ntt_fr.argtypes = [vp, vp, u32, i32]
     L.spp_msm_g1.argtypes = [vp, cp, cp, sz, i32, vp]
     _LIB = L

@@ -1,0 +1,112 @@
+"""Host-side mirrors of the reference's client-side witness-input code, executed by the HIP kernels.
+
+    rlwe_witness(...)        scripts/generate_audit.py:507-584  /  demo-frontend/app/lib/rlwe.ts:157-247
+    poseidon_hash2/4(...)    client/merkle.ts:22-38
+    ShieldedPoolMerkleTree   client/merkle.ts:146-222
+    identity_public_key(...) client/merkle.ts:98-113
+    ct_commitment(...)       ct_helper/src/main.nr:15-34
+All of them take and return Python ints / lists; field elements cross the C ABI as 32-byte big-endian.
+"""
+import ctypes
+import numpy as np
+from .lib import check
+
+TREE_DEPTH = 16
+RLWE_N, MSG_SLOTS = 1024, 64
+
+
+def _be(vals):
+    return b"".join(int(v).to_bytes(32, "big") for v in vals)
+
+
+def _unbe(buf, n):
+    return [int.from_bytes(buf[32 * i:32 * i + 32], "big") for i in range(n)]
+
+
+def rlwe_witness(ctx, pk_a, pk_b, r, e1, e2, msg):
+    """Batch form: r, e2 arrays [count,1024]; e1, msg [count,64]. Returns dict of numpy arrays + packed fields."""
+    r = np.ascontiguousarray(r, dtype=np.int8).reshape(-1, RLWE_N)
+    count = r.shape[0]
+    e1 = np.ascontiguousarray(e1, dtype=np.int8).reshape(count, MSG_SLOTS)
+    e2 = np.ascontiguousarray(e2, dtype=np.int8).reshape(count, RLWE_N)
+    msg = np.ascontiguousarray(msg, dtype=np.uint8).reshape(count, MSG_SLOTS)
+    a = np.ascontiguousarray(pk_a, dtype=np.uint32)
+    b = np.ascontiguousarray(pk_b, dtype=np.uint32)
+    c0 = np.zeros((count, MSG_SLOTS), dtype=np.uint32)
+    c1 = np.zeros((count, RLWE_N), dtype=np.uint32)
+    k0 = np.zeros((count, MSG_SLOTS), dtype=np.int32)
+    k1 = np.zeros((count, RLWE_N), dtype=np.int32)
+    packed = np.zeros((count, 157, 32), dtype=np.uint8)
+    p = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+    check(ctx.L.spp_rlwe_witness_batch(ctx.h, p(a), p(b), count, p(r), p(e1), p(e2), p(msg), p(c0), p(c1), p(k0), p(k1), p(packed)))
+    pk = [[int.from_bytes(packed[i, f].tobytes(), "big") for f in range(157)] for i in range(count)]
+    return dict(c0=c0, c1=c1, k0=k0, k1=k1, c0_packed=[x[:10] for x in pk], c1_packed=[x[10:] for x in pk])
+
+
+def poseidon_hash_batch(ctx, rows):
+    """rows: list of [a, b] or [a, b, c, d] -> list of hashes."""
+    if not rows:
+        return []
+    arity = len(rows[0])
+    out = ctypes.create_string_buffer(32 * len(rows))
+    check(ctx.L.spp_poseidon_hash_batch(ctx.h, len(rows), arity, _be(v for r in rows for v in r), ctypes.cast(out, ctypes.c_void_p)))
+    return _unbe(out.raw, len(rows))
+
+
+def poseidon_hash2(ctx, a, b):
+    return poseidon_hash_batch(ctx, [[a, b]])[0]
+
+
+def poseidon_hash4(ctx, a, b, c, d):
+    return poseidon_hash_batch(ctx, [[a, b, c, d]])[0]
+
+
+def merkle_roots(ctx, leaves, indices, siblings, depth=TREE_DEPTH):
+    count = len(leaves)
+    idx = (ctypes.c_uint64 * count)(*[int(i) for i in indices])
+    out = ctypes.create_string_buffer(32 * count)
+    check(ctx.L.spp_merkle_root_batch(ctx.h, count, depth, _be(leaves), ctypes.cast(idx, ctypes.c_void_p),
+                                      _be(s for row in siblings for s in row), ctypes.cast(out, ctypes.c_void_p)))
+    return _unbe(out.raw, count)
+
+
+class ShieldedPoolMerkleTree:
+    """client/merkle.ts:146-222 with the level recomputation done on the GPU."""
+
+    def __init__(self, ctx, depth=TREE_DEPTH):
+        self.ctx, self.depth, self.leaves = ctx, depth, []
+
+    def insert(self, commitment):
+        self.leaves.append(int(commitment))
+        return len(self.leaves) - 1
+
+    def _build(self, queries):
+        nq = len(queries)
+        q = (ctypes.c_uint64 * max(nq, 1))(*[int(i) for i in queries])
+        sib = ctypes.create_string_buffer(32 * self.depth * max(nq, 1))
+        root = ctypes.create_string_buffer(32)
+        check(self.ctx.L.spp_merkle_build(self.ctx.h, len(self.leaves), self.depth, _be(self.leaves), nq, ctypes.cast(q, ctypes.c_void_p),
+                                          ctypes.cast(sib, ctypes.c_void_p), ctypes.cast(root, ctypes.c_void_p)))
+        return int.from_bytes(root.raw, "big"), [_unbe(sib.raw[32 * self.depth * i:], self.depth) for i in range(nq)]
+
+    def getRoot(self):
+        return self._build([])[0]
+
+    def getProof(self, index):
+        return self._build([index])[1][0]
+
+
+def identity_public_keys(ctx, secret_keys):
+    count = len(secret_keys)
+    out = ctypes.create_string_buffer(64 * count)
+    check(ctx.L.spp_grumpkin_keygen_batch(ctx.h, count, _be(secret_keys), ctypes.cast(out, ctypes.c_void_p)))
+    v = _unbe(out.raw, 2 * count)
+    return [(v[2 * i], v[2 * i + 1]) for i in range(count)]
+
+
+def ct_commitments(ctx, packed_rows):
+    """packed_rows: list of lists of field elements (157 for the audit ciphertext)."""
+    count, n = len(packed_rows), len(packed_rows[0])
+    out = ctypes.create_string_buffer(32 * count)
+    check(ctx.L.spp_poseidon2_sponge_batch(ctx.h, count, n, _be(v for r in packed_rows for v in r), ctypes.cast(out, ctypes.c_void_p)))
+    return _unbe(out.raw, count)

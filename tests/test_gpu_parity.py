@@ -193,3 +193,92 @@ def test_audit_proof_bytes_match_oracle_and_verify(ctx, audit_artifacts, rlwe_pk
         assert st == [0, -4, -4]
     finally:
         h.close()
+
+
+# ---------------------------------------------------------------------------------------------- witness-input kernels
+def test_rlwe_witness_matches_reference_fixtures(ctx, rlwe_pk, rlwe_vectors):
+    """The reference's own values (tests/golden/rlwe_vectors.json, produced by importing scripts/generate_audit.py)."""
+    from spp import witness
+    r = [v["r"] for v in rlwe_vectors]
+    e1 = [v["e1"] for v in rlwe_vectors]
+    e2 = [v["e2"] for v in rlwe_vectors]
+    msg = [v["msg"] for v in rlwe_vectors]
+    out = witness.rlwe_witness(ctx, rlwe_pk["a"], rlwe_pk["b"], r, e1, e2, msg)
+    for i, v in enumerate(rlwe_vectors):
+        assert out["c0"][i].tolist() == v["c0"] and out["c1"][i].tolist() == v["c1"], v["name"]
+        assert out["k0"][i].tolist() == v["k0"] and out["k1"][i].tolist() == v["k1"], v["name"]
+        assert [hex(x) for x in out["c0_packed"][i]] == v["c0_packed"]
+        assert [hex(x) for x in out["c1_packed"][i]] == v["c1_packed"]
+
+
+def test_rlwe_witness_random_batch_and_edges(ctx, rlwe_pk):
+    import numpy as np
+    from spp import witness
+    from oracle import rlwe
+    rng = np.random.default_rng(4)
+    count = 70
+    r = rng.integers(-3, 4, size=(count, 1024), dtype=np.int8)
+    e1 = rng.integers(-3, 4, size=(count, 64), dtype=np.int8)
+    e2 = rng.integers(-3, 4, size=(count, 1024), dtype=np.int8)
+    msg = rng.integers(0, 256, size=(count, 64), dtype=np.uint8)
+    r[0] = 127; e2[0] = 127; e1[0] = 127; msg[0] = 255          # largest positive values the circuit's range proof admits
+    r[1] = -128; e2[1] = -128; e1[1] = -128; msg[1] = 0          # most negative: quotients go far below zero
+    r[2] = 0; e1[2] = 0; e2[2] = 0
+    out = witness.rlwe_witness(ctx, rlwe_pk["a"], rlwe_pk["b"], r, e1, e2, msg)
+    for i in (0, 1, 2, 3, 37, 69):
+        c0, c1, k0, k1 = rlwe.rlwe_witness(rlwe_pk["a"], rlwe_pk["b"], r[i].tolist(), e1[i].tolist(), e2[i].tolist(), msg[i].tolist())
+        assert out["c0"][i].tolist() == c0 and out["c1"][i].tolist() == c1
+        assert out["k0"][i].tolist() == k0 and out["k1"][i].tolist() == k1
+        assert out["c0_packed"][i] == rlwe.pack_values(c0) and out["c1_packed"][i] == rlwe.pack_values(c1)
+
+
+def test_poseidon_merkle_grumpkin_kernels(ctx, withdraw_kat):
+    from spp import witness
+    from oracle import hashes as H
+    from oracle.bn254 import R
+    kat = withdraw_kat
+    f = lambda k: int(kat[k], 16)
+    # the reference's golden vector (client/prover-params.toml)
+    assert witness.identity_public_keys(ctx, [f("secret_key")]) == [(f("owner_x"), f("owner_y"))]
+    assert witness.poseidon_hash2(ctx, f("owner_x"), f("owner_y")) == f("wa_commitment")
+    assert witness.poseidon_hash2(ctx, f("secret_key"), kat["index"]) == f("nullifier")
+    cm = witness.poseidon_hash4(ctx, f("owner_x"), f("owner_y"), kat["amount"], f("randomness"))
+    sib = [int(s, 16) for s in kat["siblings"]]
+    assert witness.merkle_roots(ctx, [cm], [kat["index"]], [sib]) == [f("root")]
+    t = witness.ShieldedPoolMerkleTree(ctx)
+    assert t.getRoot() == H.default_hashes()[16]                 # empty tree
+    t.insert(cm)
+    assert t.getRoot() == f("root") and t.getProof(0) == sib     # single leaf: siblings = zero-hash chain
+    # random batches against the oracle, incl. zero and p-1 operands
+    rng = random.Random(12)
+    rows2 = [[rng.randrange(R), rng.randrange(R)] for _ in range(130)] + [[0, 0], [R - 1, R - 1]]
+    assert witness.poseidon_hash_batch(ctx, rows2) == [H.poseidon_hash2(*r) for r in rows2]
+    rows4 = [[rng.randrange(R) for _ in range(4)] for _ in range(67)]
+    assert witness.poseidon_hash_batch(ctx, rows4) == [H.poseidon_hash4(*r) for r in rows4]
+    sks = [12345, 1, (1 << 128) - 1, R - 1] + [rng.randrange(R) for _ in range(20)]
+    assert witness.identity_public_keys(ctx, sks) == [H.fixed_base_scalar_mul(s) for s in sks]
+    # a 37-leaf tree: roots and proofs for several indices, ragged right edge included
+    ot = H.MerkleTree()
+    gt = witness.ShieldedPoolMerkleTree(ctx)
+    for _ in range(37):
+        v = rng.randrange(R)
+        ot.insert(v)
+        gt.insert(v)
+    assert gt.getRoot() == ot.root()
+    for idx in (0, 17, 35, 36):
+        assert gt.getProof(idx) == ot.proof(idx)
+    paths = [(ot.leaves[i], i, ot.proof(i)) for i in (3, 36)]
+    assert witness.merkle_roots(ctx, [p[0] for p in paths], [p[1] for p in paths], [p[2] for p in paths]) == [ot.root()] * 2
+
+
+def test_poseidon2_sponge_kernel(ctx, rlwe_pk):
+    from spp import witness
+    from oracle import hashes as H, rlwe
+    from oracle.bn254 import R
+    rng = random.Random(3)
+    d = rlwe.audit_inputs(rlwe_pk["a"], rlwe_pk["b"], 12345, random.Random(999))
+    rows = [d["c0_packed"] + d["c1_packed"], [rng.randrange(R) for _ in range(157)]]
+    assert witness.ct_commitments(ctx, rows) == [H.poseidon2_sponge(r) for r in rows]
+    for n in (1, 2, 3, 4):                                       # ragged absorb lengths
+        row = [rng.randrange(R) for _ in range(n)]
+        assert witness.ct_commitments(ctx, [row]) == [H.poseidon2_sponge(row)]
