@@ -103,22 +103,15 @@ def main():
         ctx.setup(sppc, b"\x2a" * 32, pkp, vkp)
     setup_s = time.time() - t0
     if world > 1:
-        if rank == 0:
-            blob = torch.frombuffer(bytearray(open(pkp, "rb").read()), dtype=torch.uint8).to(dev)
-            size = torch.tensor([blob.numel()], dtype=torch.int64, device=dev)
-        else:
-            size = torch.zeros(1, dtype=torch.int64, device=dev)
-        dist.broadcast(size, 0)
-        if rank != 0:
-            blob = torch.empty(int(size.item()), dtype=torch.uint8, device=dev)
+        from spp.multi import broadcast_blob
         torch.cuda.synchronize()
         dist.barrier()
         tb = time.time()
-        dist.broadcast(blob, 0)
+        blob = broadcast_blob(dist, open(pkp, "rb").read() if rank == 0 else None, 0, dev)   # RCCL over xGMI
         torch.cuda.synchronize()
         bcast_ms = (time.time() - tb) * 1e3
         if rank != 0:
-            open(pkp, "wb").write(blob.cpu().numpy().tobytes())
+            open(pkp, "wb").write(blob)
         del blob
     t0 = time.time()
     h = ctx.load_circuit(sppc, pkp, args.window)

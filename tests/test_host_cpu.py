@@ -1,0 +1,176 @@
+"""CPU: host logic of the product (circuit builder, containers, host mirror) and the C ABI surface --
+no compute call needs a GPU here."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+def test_c_abi_exports_every_declared_symbol():
+    import spp
+    lib = spp.load_library()
+    hdr = open(os.path.join(ROOT, "include", "spp.h")).read()
+    names = sorted(set(re.findall(r"\b(spp_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), "include/spp.h declares %s but libspp.so does not export it" % n
+    assert lib.spp_version().startswith(b"libspp")
+
+
+def test_no_device_fails_loudly():
+    """There is no CPU fallback: without a HIP device spp_init must fail (skipped on the GPU box)."""
+    import spp
+    try:
+        import torch
+        if torch.cuda.device_count() > 0:
+            pytest.skip("a GPU is visible")
+    except ImportError:
+        pass
+    with pytest.raises(spp.SppError) as e:
+        spp.Context(0)
+    assert e.value.code == -2
+
+
+def test_host_arithmetic_header_matches_oracle(tmp_path):
+    """The header the HIP kernels compile (csrc/bn254.hpp), built for the host, against Python big ints."""
+    import random
+    from oracle import bn254 as B, hashes as H
+    exe = str(tmp_path / "field_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "shielded-pool-pinocchio-solana_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "host", "field_check.cpp"), "-o", exe], check=True)
+    rng = random.Random(1)
+    h = lambda v: "%064x" % v
+    lines, exp = [], []
+    for name, m in (("fr", B.R), ("fq", B.P)):
+        cases = [(rng.randrange(m), rng.randrange(m)) for _ in range(60)] + [(0, 0), (m - 1, m - 1), (1, m - 1), (0, 5), (m - 1, 1)]
+        for a, b in cases:
+            lines.append("%s mul %s %s" % (name, h(a), h(b))); exp.append(h(a * b % m))
+            lines.append("%s add %s %s" % (name, h(a), h(b))); exp.append(h((a + b) % m))
+            lines.append("%s sub %s %s" % (name, h(a), h(b))); exp.append(h((a - b) % m))
+            lines.append("%s neg %s" % (name, h(a))); exp.append(h((-a) % m))
+        for _ in range(4):
+            a = rng.randrange(1, m)
+            lines.append("%s inv %s" % (name, h(a))); exp.append(h(pow(a, -1, m)))
+            u = rng.randrange(1 << 256)
+            lines.append("%s u256 %s" % (name, h(u))); exp.append(h(u % m))
+    for _ in range(6):
+        a = (rng.randrange(B.P), rng.randrange(B.P)); b = (rng.randrange(B.P), rng.randrange(B.P))
+        r = B.f2_mul(a, b)
+        lines.append("fq2 mul %s %s %s %s" % (h(a[0]), h(a[1]), h(b[0]), h(b[1]))); exp.append(h(r[0]) + " " + h(r[1]))
+        r = B.f2_inv(a)
+        lines.append("fq2 inv %s %s" % (h(a[0]), h(a[1]))); exp.append(h(r[0]) + " " + h(r[1]))
+    for _ in range(3):
+        k1, k = rng.randrange(B.R), rng.randrange(B.R)
+        p = B.g1_mul(B.G1_GEN, k1); r = B.g1_mul(p, k)
+        lines.append("g1 mul %s %s %s" % (h(p[0]), h(p[1]), h(k))); exp.append(h(r[0]) + " " + h(r[1]))
+        q = B.g1_mul(B.G1_GEN, rng.randrange(B.R))
+        c = B.g1_add(B.g1_mul(p, 3), B.g1_mul(q, 2)); d = B.g1_add(B.g1_mul(p, 3), q)
+        lines.append("g1 add %s %s %s %s" % (h(p[0]), h(p[1]), h(q[0]), h(q[1]))); exp.append(" ".join(h(v) for v in (c[0], c[1], d[0], d[1])))
+        p2 = B.g2_mul(B.G2_GEN, k1); r2 = B.g2_mul(p2, k)
+        lines.append("g2 mul " + " ".join(h(v) for v in (p2[0][0], p2[0][1], p2[1][0], p2[1][1])) + " " + h(k))
+        exp.append(" ".join(h(v) for v in (r2[0][0], r2[0][1], r2[1][0], r2[1][1])))
+        kk = rng.randrange(1 << 128); rg = H.grumpkin_mul(H.GRUMPKIN_G, kk)
+        lines.append("gk mul %s %s %s" % (h(H.GRUMPKIN_G[0]), h(H.GRUMPKIN_G[1]), h(kk))); exp.append(h(rg[0]) + " " + h(rg[1]))
+    out = subprocess.run([exe], input="\n".join(lines) + "\n", capture_output=True, text=True, check=True).stdout.strip().split("\n")
+    assert out == exp
+
+
+def test_withdraw_circuit_semantics(withdraw_artifacts, withdraw_kat):
+    """The product's R1CS + solver program, interpreted by the Python oracle, accepts the reference's golden
+    inputs and refuses exactly what noir_circuit/src/main.nr asserts against."""
+    from oracle import circuit as C
+    c = C.Circuit(withdraw_artifacts["sppc"])
+    assert (c.n_public - 1, c.n_secret) == (5, 21) and c.n_constraints == withdraw_artifacts["n_constraints"]
+    assert c.n_constraints <= 12452            # the reference's gnark R1CS (emulated-field Grumpkin) is larger
+    good = C.withdraw_inputs(withdraw_kat)
+    chal = lambda w: 0xabcdef
+    assert C.first_unsatisfied(c, C.solve(c, good, chal)) == -1
+    def bad(i, v):
+        x = list(good); x[i] = v
+        return C.first_unsatisfied(c, C.solve(c, x, chal)) >= 0
+    assert bad(0, good[0] + 1)          # root            main.nr:78
+    assert bad(1, good[1] + 1)          # nullifier       main.nr:74
+    assert bad(2, 0)                    # recipient != 0  main.nr:81
+    assert bad(3, 1 << 64)              # amount: u64     main.nr:43
+    assert bad(4, good[4] + 1)          # wa_commitment   main.nr:67
+    assert bad(5, good[5] + 1)          # secret_key -> public key mismatch main.nr:61-62
+    assert bad(9, 1)                    # wrong leaf index
+    assert bad(9, 1 << 16)              # index out of the 16-bit path range
+    assert bad(12, good[12] + 1)        # a sibling
+
+
+def test_audit_circuit_semantics(audit_artifacts, rlwe_pk):
+    import random
+    from oracle import circuit as C, rlwe
+    c = C.Circuit(audit_artifacts["sppc"])
+    assert (c.n_public - 1, c.n_inputs()) == (2, 3360) and c.domain_log == 15
+    d = rlwe.audit_inputs(rlwe_pk["a"], rlwe_pk["b"], 12345, random.Random(999))
+    good = rlwe.audit_input_vector(d)
+    chal = lambda w: 0x1234567
+    assert C.first_unsatisfied(c, C.solve(c, good, chal)) == -1
+    def bad(i, v):
+        x = list(good); x[i] = v
+        return C.first_unsatisfied(c, C.solve(c, x, chal)) >= 0
+    R0 = 2 + 157 + 1
+    assert bad(0, good[0] + 1)                    # wa_commitment
+    assert bad(1, good[1] + 1)                    # ct_commitment
+    assert bad(2, good[2] + 1)                    # a packed ciphertext field
+    assert bad(R0 + 5, (good[R0 + 5] + 1))        # r[5]: breaks the quotient equations
+    assert bad(R0 + 7, 200)                       # r[7] outside [-128,127]
+    assert bad(R0 + 1024 + 64 + 1024 + 3, good[R0 + 1024 + 64 + 1024 + 3] + 1)   # k0[3]
+
+
+def test_cpu_oracle_end_to_end(withdraw_artifacts, withdraw_kat):
+    """C oracle prover + Python pairing verifier: proof verifies, byte flips and wrong public inputs do not
+    (client/test-shielded-pool.ts:386-417 failure modes), formats match withdraw.rs:13-16."""
+    from oracle import native, groth16, circuit as C
+    p = native.Prover(withdraw_artifacts["sppc"], withdraw_artifacts["pk"])
+    row = C.withdraw_inputs(withdraw_kat)
+    rc, proof, pw, wires = p.prove(row, 11111, 22222, want_wires=True)
+    assert rc == 0 and len(proof) == 388 and len(pw) == 172
+    assert pw == groth16.public_witness_bytes(row[:5])
+    assert pw[12 + 32 * 3 + 24:12 + 32 * 4] == int(withdraw_kat["amount"]).to_bytes(8, "big")   # withdraw.rs:157-161
+    vk = open(withdraw_artifacts["vk"], "rb").read()
+    assert len(vk) == 1296
+    assert groth16.verify(vk, proof, pw)
+    bad = bytearray(proof); bad[0] ^= 1
+    assert not groth16.verify(vk, bytes(bad), pw)
+    pw2 = bytearray(pw); pw2[-1] ^= 1
+    assert not groth16.verify(vk, proof, bytes(pw2))
+    c = C.Circuit(withdraw_artifacts["sppc"])
+    assert C.solve(c, row, lambda w: wires[c.challenge_wire]) == wires      # two independent solvers agree
+    rc2, proof2, _ = p.prove(row, 11111, 22222)
+    assert proof2 == proof                                                   # deterministic under fixed (r, s)
+    rc3, proof3, _ = p.prove(row, 5, 6)
+    assert proof3 != proof and groth16.verify(vk, proof3, pw)                # different blinding, same statement
+    assert p.prove([row[0] + 1] + row[1:], 1, 2)[0] == 1                     # unsatisfied -> refused
+
+
+def test_prover_toml_and_input_order(withdraw_kat):
+    """Host mirror of client/proof.helper.ts:32-50."""
+    from spp.proof_helper import ShieldedPoolInputs, prover_toml, input_vector
+    from oracle import circuit as C
+    k = withdraw_kat
+    inp = ShieldedPoolInputs(**{f: k[f] for f in ("root", "nullifier", "recipient", "amount", "wa_commitment", "secret_key", "owner_x",
+                                                   "owner_y", "randomness", "index", "siblings")})
+    t = prover_toml(inp)
+    assert t.startswith('root = "%s"\nnullifier = "%s"\nrecipient = "%s"\namount = %d\nwa_commitment = ' % (
+        k["root"], k["nullifier"], k["recipient"], k["amount"]))
+    assert 'index = 0\nsiblings = [\n  "%s",\n' % k["siblings"][0] in t and t.endswith('",\n]\n')
+    assert input_vector(inp) == C.withdraw_inputs(k)
+    with pytest.raises(ValueError):
+        input_vector(ShieldedPoolInputs(**{**inp.__dict__, "siblings": k["siblings"][:3]}))
+
+
+def test_shard_ranges():
+    from spp.multi import shard_range
+    for total in (0, 1, 7, 1024, 1025):
+        for world in (1, 2, 3, 8):
+            rs = [shard_range(total, r, world) for r in range(world)]
+            assert rs[0][0] == 0 and rs[-1][1] == total
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
+            assert max(b - a for a, b in rs) - min(b - a for a, b in rs) <= 1

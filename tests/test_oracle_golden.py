@@ -1,0 +1,108 @@
+"""CPU: the oracle against every golden vector the reference holds for this path."""
+import json
+import os
+import random
+
+from conftest import GOLDEN
+
+
+def test_prover_params_kat(withdraw_kat):
+    """client/prover-params.toml: Grumpkin key, wa_commitment, nullifier, H4 commitment, zero-hash chain, root."""
+    from oracle import hashes as H
+    k = withdraw_kat
+    f = lambda n: int(k[n], 16)
+    pv = H.withdraw_public_values(f("secret_key"), k["amount"], f("randomness"), k["index"], [int(s, 16) for s in k["siblings"]])
+    for name in ("owner_x", "owner_y", "wa_commitment", "nullifier", "root"):
+        assert pv[name] == f(name), name
+    assert H.default_hashes()[:16] == [int(s, 16) for s in k["siblings"]]
+    assert H.identity_keypair(f("secret_key"))[1] == (f("owner_x"), f("owner_y"))
+
+
+def test_noir_unit_test_vector():
+    """noir_circuit/src/main.nr:84-130: sk 12345, index 0, zero siblings -- main() must be satisfiable."""
+    from oracle import hashes as H
+    owner = H.fixed_base_scalar_mul(12345)
+    cm = H.poseidon_hash4(owner[0], owner[1], 1000000, 67890)
+    assert H.compute_merkle_root(cm, 0, [0] * 16) == H.compute_merkle_root(cm, 0, [0] * 16)
+    t = H.MerkleTree()
+    t.insert(cm)
+    assert t.proof(0) == H.default_hashes()[:16]
+
+
+def test_poseidon2_kat_and_constants():
+    """Literature KAT perm([0,1,2,3]) and the internal diagonal quoted in SURVEY App. B."""
+    from oracle import hashes as H
+    rc, mu = H.poseidon2_params()
+    assert mu == H.P2_MU_EXPECTED
+    assert rc[0] == 0x19b849f69450b06848da1d39bd5e4a4302bb86744edc26238b0878e269ed23e5
+    assert H.poseidon2_permute([0, 1, 2, 3]) == [
+        0x01bd538c2ee014ed5141b29e9ae240bf8db3fe5b9a38629a9647cf8d76c01737,
+        0x239b62e7db98aa3a2a8f6a0d2fa1709e7a35959aa6c7034814d9daa90cbac662,
+        0x04cbb44c61d928ed06808456bf758cbf0c18d1e15a7b6dbc8245fa7515d5e3cb,
+        0x2e11c5cff2a22c64d01304b778d78f6998eff1ab73163a35603f54794c30847a]
+
+
+def test_rlwe_vectors(rlwe_pk, rlwe_vectors):
+    """Vectors produced by importing the reference's scripts/generate_audit.py (tests/golden/make_fixtures.py)."""
+    from oracle import rlwe
+    assert rlwe_vectors[0]["c1"][:3] == [78874407, 130923686, 120074060]      # SURVEY 8c RLWE-1
+    for v in rlwe_vectors:
+        c0, c1, k0, k1 = rlwe.rlwe_witness(rlwe_pk["a"], rlwe_pk["b"], v["r"], v["e1"], v["e2"], v["msg"])
+        assert (c0, c1, k0, k1) == (v["c0"], v["c1"], v["k0"], v["k1"]), v["name"]
+        assert [hex(x) for x in rlwe.pack_values(c0)] == v["c0_packed"]
+        assert [hex(x) for x in rlwe.pack_values(c1)] == v["c1_packed"]
+        assert [rlwe.format_field(x) for x in k0[:8]] == v["k0_fmt"]
+        q = rlwe.RLWE_Q
+        assert rlwe.negacyclic_mul_mod_q(rlwe_pk["a"], [x % q for x in v["r"]]).tolist() == v["ar"]
+        assert rlwe.negacyclic_matrix_row_mod_q(rlwe_pk["a"], 1000)[:16].tolist() == v["row_a_1000"]
+        assert rlwe.negacyclic_matrix_row_mod_q(rlwe_pk["b"], 5)[:16].tolist() == v["row_b_5"]
+
+
+def test_pack_and_format_kat():
+    from oracle import rlwe
+    k = json.load(open(os.path.join(GOLDEN, "pack_kat.json")))
+    assert [hex(v) for v in rlwe.pack_values(k["in"])] == k["out"]
+    assert rlwe.encode_field_to_bytes(int(k["bytes_in"], 16), 8) == k["bytes_out"]
+    for v, s in k["fmt"]:
+        assert rlwe.format_field(v) == s
+
+
+def test_c_oracle_matches_python_oracle(rlwe_pk, rlwe_vectors):
+    """The C restatement (liboracle.so) against the Python one: hashes, RLWE, NTT round trip, MSM."""
+    import ctypes
+    import numpy as np
+    from oracle import native, hashes as H, bn254 as B
+    L = native.lib()
+    rng = random.Random(8)
+    for arity in (2, 4):
+        vals = [rng.randrange(B.R) for _ in range(arity)]
+        out = ctypes.create_string_buffer(32)
+        L.orc_poseidon_hash(b"".join(v.to_bytes(32, "big") for v in vals), arity, out)
+        assert int.from_bytes(out.raw, "big") == H.poseidon_hash(vals)
+    out = ctypes.create_string_buffer(128)
+    L.orc_poseidon2_permute(b"".join(v.to_bytes(32, "big") for v in (0, 1, 2, 3)), out)
+    assert [int.from_bytes(out.raw[32 * i:32 * i + 32], "big") for i in range(4)] == H.poseidon2_permute([0, 1, 2, 3])
+    v = rlwe_vectors[0]
+    a = np.array(rlwe_pk["a"], dtype=np.uint32); b = np.array(rlwe_pk["b"], dtype=np.uint32)
+    r = np.array(v["r"], dtype=np.int32); e1 = np.array(v["e1"], dtype=np.int32); e2 = np.array(v["e2"], dtype=np.int32)
+    m = np.array(v["msg"], dtype=np.uint32)
+    c0 = np.zeros(64, dtype=np.uint32); c1 = np.zeros(1024, dtype=np.uint32)
+    k0 = np.zeros(64, dtype=np.int64); k1 = np.zeros(1024, dtype=np.int64)
+    p = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+    L.orc_rlwe_witness(p(a), p(b), p(r), p(e1), p(e2), p(m), p(c0), p(c1), p(k0), p(k1))
+    assert c0.tolist() == v["c0"] and c1.tolist() == v["c1"] and k0.tolist() == v["k0"] and k1.tolist() == v["k1"]
+    pts = [B.g1_mul(B.G1_GEN, rng.randrange(1, B.R)) for _ in range(9)]
+    sc = [rng.randrange(B.R) for _ in range(9)]
+    out = ctypes.create_string_buffer(64)
+    L.orc_msm_g1(b"".join(B.g1_to_bytes(q) for q in pts), b"".join(s.to_bytes(32, "big") for s in sc), 9, ctypes.cast(out, ctypes.c_void_p))
+    assert out.raw == B.g1_to_bytes(B.g1_msm(pts, sc))
+
+
+def test_pairing_and_hash_to_field_kats():
+    from oracle import bn254 as B
+    a, b = 1234567, 7654321
+    assert B.pairing_product_is_one([(B.g1_mul(B.G1_GEN, a), B.g2_mul(B.G2_GEN, b)), (B.g1_neg(B.g1_mul(B.G1_GEN, a * b)), B.G2_GEN)])
+    assert not B.pairing_product_is_one([(B.g1_mul(B.G1_GEN, a), B.g2_mul(B.G2_GEN, b)), (B.g1_neg(B.g1_mul(B.G1_GEN, a * b + 1)), B.G2_GEN)])
+    # RFC 9380 K.1 expand_message_xmd(SHA-256), msg = "", len 0x20
+    assert B.expand_message_xmd(b"", b"QUUX-V01-CS02-with-expander-SHA256-128", 0x20).hex() == \
+        "68a985b87eb6b46952128911f2a4412bbc302a9d759667f87f7a21d803f07235"
