@@ -1,0 +1,90 @@
+"""The TypeScript-side boundary: N-API addon + CommonJS twin of client/proof.helper.ts and generate-proof-hex.ts.
+Runs under node (v12 in this image); skipped when node or its headers are absent."""
+import json
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+NODE_DIR = os.path.join(ROOT, "shielded-pool-pinocchio-solana_amd", "node")
+pytestmark = pytest.mark.skipif(shutil.which("node") is None or not os.path.exists("/usr/include/node/node_api.h"),
+                                reason="node toolchain not present")
+
+
+@pytest.fixture(scope="module")
+def addon():
+    subprocess.run(["make", "-C", NODE_DIR, "-s"], check=True)
+    return os.path.join(NODE_DIR, "proof.helper.js")
+
+
+def _node(script):
+    return subprocess.run(["node", "-e", script], capture_output=True, text=True)
+
+
+def test_addon_exports_and_prover_toml(addon, withdraw_kat, tmp_path):
+    from spp.proof_helper import ShieldedPoolInputs, prover_toml
+    k = withdraw_kat
+    fields = ("root", "nullifier", "recipient", "amount", "wa_commitment", "secret_key", "owner_x", "owner_y", "randomness", "index", "siblings")
+    script = """
+      const h = require(%s);
+      const inputs = %s;
+      process.stdout.write(JSON.stringify({
+        fns: ['init','buildCircuit','setup','loadCircuit','circuitInfo','proveBatch','version'].map(n => typeof h.addon[n]),
+        version: h.addon.version(), toml: h.proverToml(inputs), n: h.addon.buildCircuit(1, %s),
+        amount: h.toField32(inputs.amount).toString('hex') }));
+    """ % (json.dumps(addon), json.dumps({f: k[f] for f in fields}), json.dumps(str(tmp_path / "w.sppc")))
+    r = _node(script)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)
+    assert out["fns"] == ["function"] * 7 and out["version"].startswith("libspp")
+    assert out["toml"] == prover_toml(ShieldedPoolInputs(**{f: k[f] for f in fields}))     # proof.helper.ts:32-50
+    assert out["n"] > 5000 and int(out["amount"], 16) == k["amount"]
+
+
+def test_generate_proof_hex_twins_agree(tmp_path):
+    from spp import generate_proof_hex as G
+    root = tmp_path
+    js = os.path.join(NODE_DIR, "generate-proof-hex.js")
+    r = subprocess.run(["node", js, str(root)], capture_output=True, text=True)
+    code, out, err = G.render(str(root))
+    assert r.returncode == 1 == code and r.stdout == out and r.stderr == err       # generate-proof-hex.ts:36-44
+    assert "Error: Withdraw proof file not found at" in err and "  sunspot prove target/shielded_pool_verifier.json ..." in err
+    for d, base in (("noir_circuit", "shielded_pool_verifier"), ("audit_circuit", "rlwe_audit")):
+        os.makedirs(root / d / "target")
+        (root / d / "target" / (base + ".proof")).write_bytes(bytes(range(97)) * 4)
+        (root / d / "target" / (base + ".pw")).write_bytes(b"\x00\x00\x00\x05" + bytes(72))
+    r = subprocess.run(["node", js, str(root)], capture_output=True, text=True)
+    code, out, err = G.render(str(root))
+    assert r.returncode == 0 == code and r.stdout == out
+    assert "1. WITHDRAW PROOF (hex):\n" + "=" * 60 + "\n\n0x000102" in out                 # :82-87
+    assert "Withdraw proof size: 388 bytes" in out and "4. Copy AUDIT PUBLIC WITNESS hex -> paste into 'Audit Public Witness (hex)' field" in out
+
+
+@pytest.mark.gpu
+def test_generate_proof_through_node_on_gpu(addon, withdraw_artifacts, withdraw_kat, tmp_path):
+    """generateProof(config, inputs) as client/test-shielded-pool.ts:246 calls it; files as proof.helper.ts:68-69."""
+    from oracle import groth16
+    cdir = tmp_path / "noir_circuit"
+    os.makedirs(cdir / "target")
+    shutil.copy(withdraw_artifacts["sppc"], cdir / "target" / "shielded_pool_verifier.sppc")
+    shutil.copy(withdraw_artifacts["pk"], cdir / "target" / "shielded_pool_verifier.pk")
+    fields = ("root", "nullifier", "recipient", "amount", "wa_commitment", "secret_key", "owner_x", "owner_y", "randomness", "index", "siblings")
+    script = """
+      const h = require(%s);
+      const r = h.generateProof({circuitDir: %s, circuitName: 'shielded_pool_verifier'}, %s);
+      let threw = false;
+      try { h.generateProof({circuitDir: %s, circuitName: 'shielded_pool_verifier'}, Object.assign({}, %s, {recipient: '0x0'})); } catch (e) { threw = /libspp error -4/.test(e.message); }
+      process.stdout.write(JSON.stringify({proof: r.proof.toString('hex'), pw: r.publicWitness.toString('hex'), threw}));
+    """ % (json.dumps(addon), json.dumps(str(cdir)), json.dumps({f: withdraw_kat[f] for f in fields}), json.dumps(str(cdir)),
+           json.dumps({f: withdraw_kat[f] for f in fields}))
+    r = _node(script)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)
+    proof, pw = bytes.fromhex(out["proof"]), bytes.fromhex(out["pw"])
+    assert len(proof) == 388 and len(pw) == 172 and out["threw"]
+    assert (cdir / "target" / "shielded_pool_verifier.proof").read_bytes() == proof
+    assert (cdir / "Prover.toml").exists()
+    assert groth16.verify(open(withdraw_artifacts["vk"], "rb").read(), proof, pw)
