@@ -68,8 +68,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="proofs per GPU per step")
     ap.add_argument("--circuit", default=os.environ.get("SPP_BENCH_CIRCUIT", "withdraw"), choices=["withdraw", "audit"])
-    ap.add_argument("--window", type=int, default=int(os.environ.get("SPP_WINDOW", "10")))
+    ap.add_argument("--window", type=int, default=int(os.environ.get("SPP_WINDOW", "0")), help="MSM window bits; 0 = auto (largest tables within the HBM budget)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the second circuit")
     args = ap.parse_args()
 
     import torch
@@ -85,132 +86,157 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import spp
-    from oracle import native, circuit as C
+    from oracle import native
 
-    tmp = tempfile.mkdtemp(prefix="spp_bench_%d_" % rank)
-    sppc, pkp, vkp = (os.path.join(tmp, "c." + e) for e in ("sppc", "pk", "vk"))
-    if args.circuit == "withdraw":
-        spp.build_circuit(1, sppc)
-    else:
-        pk = json.load(open(os.path.join(ROOT, "tests", "golden", "rlwe_pk.json")))
-        spp.build_circuit(2, sppc, aux=list(pk["a"]) + list(pk["b"]))
-    ctx = spp.Context(local_rank)
+    def run_circuit(circuit, B, steps, warmup, want_cpu):
+        """Returns the result dict for one circuit (rank 0) or None (other ranks)."""
+        tmp = tempfile.mkdtemp(prefix="spp_bench_%d_" % rank)
+        sppc, pkp, vkp = (os.path.join(tmp, "c." + e) for e in ("sppc", "pk", "vk"))
+        if circuit == "withdraw":
+            spp.build_circuit(1, sppc)
+        else:
+            pk = json.load(open(os.path.join(ROOT, "tests", "golden", "rlwe_pk.json")))
+            spp.build_circuit(2, sppc, aux=list(pk["a"]) + list(pk["b"]))
+        ctx = spp.Context(local_rank)
+        # ---- proving key: GPU setup on rank 0, one RCCL broadcast over xGMI ----
+        t0 = time.time()
+        bcast_ms = 0.0
+        if rank == 0:
+            ctx.setup(sppc, b"\x2a" * 32, pkp, vkp)
+        setup_s = time.time() - t0
+        if world > 1:
+            from spp.multi import broadcast_blob
+            torch.cuda.synchronize()
+            dist.barrier()
+            tb = time.time()
+            blob = broadcast_blob(dist, open(pkp, "rb").read() if rank == 0 else None, 0, dev)   # RCCL over xGMI
+            torch.cuda.synchronize()
+            bcast_ms = (time.time() - tb) * 1e3
+            if rank != 0:
+                open(pkp, "wb").write(blob)
+            del blob
+        t0 = time.time()
+        h = ctx.load_circuit(sppc, pkp, args.window)
+        load_s = time.time() - t0
 
-    # ---- proving key: GPU setup on rank 0, one RCCL broadcast over xGMI ----
-    t0 = time.time()
-    bcast_ms = 0.0
-    if rank == 0:
-        ctx.setup(sppc, b"\x2a" * 32, pkp, vkp)
-    setup_s = time.time() - t0
-    if world > 1:
-        from spp.multi import broadcast_blob
+        # ---- synthetic batch, resident in HBM ----
+        rows = synth_withdraw_rows(B) if circuit == "withdraw" else synth_audit_rows(B)
+        inp = torch.frombuffer(bytearray(b"".join(int(v).to_bytes(32, "big") for r in rows for v in r)), dtype=torch.uint8).to(dev)
+        rs_bytes = b"".join((1000003 * (rank * B + i) + 17).to_bytes(32, "big") + (998244353 * (rank * B + i) + 29).to_bytes(32, "big")
+                            for i in range(B))
+        rs = torch.frombuffer(bytearray(rs_bytes), dtype=torch.uint8).to(dev)
+        # two output sets: consecutive batches are pipelined on two streams inside libspp
+        proofs = [torch.zeros(B * 388, dtype=torch.uint8, device=dev) for _ in range(2)]
+        pws = [torch.zeros(B * h.pw_len, dtype=torch.uint8, device=dev) for _ in range(2)]
+        status = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)]
         torch.cuda.synchronize()
-        dist.barrier()
-        tb = time.time()
-        blob = broadcast_blob(dist, open(pkp, "rb").read() if rank == 0 else None, 0, dev)   # RCCL over xGMI
+        step_no = [0]
+
+        def step():
+            k = step_no[0] & 1
+            step_no[0] += 1
+            h.prove_batch_device(B, inp.data_ptr(), rs.data_ptr(), proofs[k].data_ptr(), pws[k].data_ptr(), status[k].data_ptr())
+
+        for _ in range(warmup):
+            step()
+        h.sync()
         torch.cuda.synchronize()
-        bcast_ms = (time.time() - tb) * 1e3
-        if rank != 0:
-            open(pkp, "wb").write(blob)
-        del blob
-    t0 = time.time()
-    h = ctx.load_circuit(sppc, pkp, args.window)
-    load_s = time.time() - t0
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        acc = {"kern_ms": 0.0, "kern_n": 0, "stage": [0.0] * 7}
 
-    # ---- synthetic batch, resident in HBM ----
-    B = args.batch
-    rows = synth_withdraw_rows(B) if args.circuit == "withdraw" else synth_audit_rows(B)
-    inp = torch.frombuffer(bytearray(b"".join(int(v).to_bytes(32, "big") for r in rows for v in r)), dtype=torch.uint8).to(dev)
-    rs_bytes = b"".join((1000003 * (rank * B + i) + 17).to_bytes(32, "big") + (998244353 * (rank * B + i) + 29).to_bytes(32, "big")
-                        for i in range(B))
-    rs = torch.frombuffer(bytearray(rs_bytes), dtype=torch.uint8).to(dev)
-    # two output sets: consecutive batches are pipelined on two streams inside libspp
-    proofs = [torch.zeros(B * 388, dtype=torch.uint8, device=dev) for _ in range(2)]
-    pws = [torch.zeros(B * h.pw_len, dtype=torch.uint8, device=dev) for _ in range(2)]
-    status = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)]
-    torch.cuda.synchronize()
-    step_no = [0]
+        def take(tm):
+            acc["kern_ms"] += tm[7] * tm[8]
+            acc["kern_n"] += int(tm[8])
+            for i in range(7):
+                acc["stage"][i] += tm[i]
 
-    def step():
-        k = step_no[0] & 1
-        step_no[0] += 1
-        h.prove_batch_device(B, inp.data_ptr(), rs.data_ptr(), proofs[k].data_ptr(), pws[k].data_ptr(), status[k].data_ptr())
+        for it in range(steps):
+            step()
+            if it >= 1:
+                take(h.last_timings(1))   # HIP events of the previous step; the step just enqueued keeps the GPU busy
+        h.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        assert int(status[0].abs().sum().item()) + int(status[1].abs().sum().item()) == 0, "some synthetic proofs were refused"
+        take(h.last_timings(0))           # events of the last timed step (already complete)
 
-    for _ in range(args.warmup):
-        step()
-    h.sync()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    kern_ms, kern_n = 0.0, 0
-    stage = [0.0] * 7
-    def take(tm):
-        nonlocal kern_ms, kern_n
-        kern_ms += tm[7] * tm[8]
-        kern_n += int(tm[8])
-        for i in range(7):
-            stage[i] += tm[i]
+        out = None
+        if rank == 0:
+            total_proofs = B * world * steps
+            value = total_proofs / elapsed
+            sizes = h.msm_sizes()
+            g1_sizes = sizes[:6]
+            # algorithmic bytes of one k_msm_fixed<G1> launch: every base once (64 B) + one 32 B scalar per (base, proof)
+            alg_bytes = sum(64 * n + 32 * n * B for n in g1_sizes) / len(g1_sizes)
+            avg_ms = acc["kern_ms"] / max(acc["kern_n"], 1)
+            achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            traffic = None
+            try:   # PMC pass of the same workload, committed under profiles/ (rocprofv3 --pmc cannot run inside this process)
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_latest.json")))
+                if pmc.get("circuit") == circuit and pmc.get("batch") == B and pmc.get("window_bits") == h.window_bits:
+                    traffic = pmc["k_msm_fixed_g1_hbm_bytes_per_launch"]
+            except Exception:
+                pass
+            out = {
+                "value": round(value, 3), "ms_per_step": round(elapsed / steps * 1e3, 3),
+                "config": {"workload": "%s, batch of %d independent proofs per GPU per step" % (
+                    "noir_circuit withdraw (Poseidon Merkle depth 16 + Grumpkin)" if circuit == "withdraw" else "audit_circuit (RLWE, const-PK)", B),
+                    "circuit": circuit, "n_constraints": h.n_constraints, "n_wires": h.n_wires, "domain": 1 << h.domain_log,
+                    "batch_per_gpu": B, "window_bits": h.window_bits, "msm_sizes": dict(zip(["A", "B1", "K", "Z", "CB", "CS", "B2(G2)"], sizes)),
+                    "table_bytes": h.table_bytes, "parallelism": "independent proofs x%d" % world,
+                    "pk_bcast_ms": round(bcast_ms, 3), "setup_s": round(setup_s, 2), "load_s": round(load_s, 2)},
+                "stage_ms_per_step": {k: round(v / steps, 3) for k, v in zip(
+                    ["solve+commit", "matrix_eval", "ntt_qap", "msm_g1", "msm_g2", "assemble", "total"], acc["stage"])},
+                "roofline": {"bound": "hbm", "kernel": "k_msm_fixed<Fq>", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "alg_bytes_per_launch": int(alg_bytes),
+                             "avg_launch_ms": round(avg_ms, 4), "launches_timed": acc["kern_n"],
+                             "note": "integer-VALU bound (5.7K instructions per mixed addition); HBM fraction reported as mandated"},
+            }
+            if want_cpu:
+                orc = native.Prover(sppc, pkp)
+                cores = native.max_threads()
+                # throughput mode: one proof per host thread, rounds of `cores` proofs until ~10 s have elapsed
+                t1 = time.perf_counter()
+                done = 0
+                while done == 0 or (time.perf_counter() - t1 < 10.0 and done < 4096):
+                    batch = [rows[(done + i) % len(rows)] for i in range(cores)]
+                    rc, _, _ = native.prove_many(orc, batch, [(7 + done + i, 11 + done + i) for i in range(cores)])
+                    assert rc == 0
+                    done += cores
+                dt = time.perf_counter() - t1
+                out["cpu_baseline"] = {"value": round(done / dt, 3), "unit": "proofs/s", "cores": cores, "kind": "port",
+                                       "sample": "%d %s proofs, one per host thread, oracle C/OpenMP prover (stands in for the Sunspot "
+                                                 "Go/CPU path, which cannot run here: no Go toolchain, no pk)" % (done, circuit)}
+        h.close()
+        ctx.close()
+        del inp, rs, proofs, pws, status
+        torch.cuda.empty_cache()
+        return out
 
-    for it in range(args.steps):
-        step()
-        if it >= 1:
-            take(h.last_timings(1))   # HIP events of the previous step; the step just enqueued keeps the GPU busy
-    h.sync()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert int(status[0].abs().sum().item()) + int(status[1].abs().sum().item()) == 0, "some synthetic proofs were refused"
-    take(h.last_timings(0))           # events of the last timed step (already complete)
-
+    main_res = run_circuit(args.circuit, args.batch, args.steps, args.warmup, not args.no_cpu_baseline)
+    # the other circuit of BASELINE.json's metric, as a secondary figure (single GPU runs only)
+    other = None
+    if world == 1 and not args.no_secondary:
+        oc = "audit" if args.circuit == "withdraw" else "withdraw"
+        other = run_circuit(oc, 128 if oc == "audit" else 256, 3, 1, not args.no_cpu_baseline)
     if rank == 0:
-        total_proofs = B * world * args.steps
-        value = total_proofs / elapsed
-        sizes = h.msm_sizes()
-        g1_sizes = sizes[:6]
-        # algorithmic bytes of one k_msm_fixed<G1> launch: every base once (64 B) + one 32 B scalar per (base, proof)
-        alg_bytes = sum(64 * n + 32 * n * B for n in g1_sizes) / len(g1_sizes)
-        avg_ms = kern_ms / max(kern_n, 1)
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        out = {
-            "metric": "Groth16 proofs/sec", "value": round(value, 3), "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32x8 (254-bit Montgomery integers)", "data": "synthetic",
-            "config": {"workload": "%s circuit, batch of %d independent proofs per GPU per step" % (
-                "noir_circuit withdraw (Poseidon Merkle depth 16 + Grumpkin)" if args.circuit == "withdraw" else "audit_circuit (RLWE)", B),
-                "circuit": args.circuit, "n_constraints": h.n_constraints, "n_wires": h.n_wires, "domain": 1 << h.domain_log,
-                "batch_per_gpu": B, "window_bits": h.window_bits, "msm_sizes": dict(zip(["A", "B1", "K", "Z", "CB", "CS", "B2(G2)"], sizes)), "table_bytes": h.table_bytes, "parallelism": "independent proofs x%d" % world,
-                "pk_bcast_ms": round(bcast_ms, 3), "setup_s": round(setup_s, 2), "load_s": round(load_s, 2)},
-            "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in zip(
-                ["solve+commit", "matrix_eval", "ntt_qap", "msm_g1", "msm_g2", "assemble", "total"], stage)},
-            "roofline": {"bound": "hbm", "kernel": "k_msm_fixed<Fq>", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "alg_bytes_per_launch": int(alg_bytes),
-                         "avg_launch_ms": round(avg_ms, 4), "launches_timed": kern_n,
-                         "note": "integer-ALU bound (v_mad_u64_u32), HBM fraction reported as mandated"},
-        }
-        if not args.no_cpu_baseline:
-            orc = native.Prover(sppc, pkp)
-            cores = native.max_threads()
-            # throughput mode: one proof per host thread, rounds of `cores` proofs until ~12 s have elapsed
-            t1 = time.perf_counter()
-            done = 0
-            while done == 0 or (time.perf_counter() - t1 < 12.0 and done < 4096):
-                batch = [rows[(done + i) % len(rows)] for i in range(cores)]
-                rc, _, _ = native.prove_many(orc, batch, [(7 + done + i, 11 + done + i) for i in range(cores)])
-                assert rc == 0
-                done += cores
-            dt = time.perf_counter() - t1
-            out["cpu_baseline"] = {"value": round(done / dt, 3), "unit": "proofs/s", "cores": cores, "kind": "port",
-                                   "sample": "%d %s proofs, one per host thread, oracle C/OpenMP prover (stands in for the Sunspot "
-                                             "Go/CPU path, which cannot run here: no Go toolchain, no pk)" % (done, args.circuit)}
-        print(json.dumps(out), flush=True)
-    h.close()
-    ctx.close()
+        line = {"metric": "Groth16 proofs/sec", "value": main_res["value"], "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "u32x8 (254-bit Montgomery integers)", "data": "synthetic"}
+        for k in ("config", "stage_ms_per_step", "roofline", "cpu_baseline"):
+            if k in main_res:
+                line[k] = main_res[k]
+        if other is not None:
+            line["secondary_" + ("audit" if args.circuit == "withdraw" else "withdraw") + "_circuit"] = other
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

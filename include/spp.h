@@ -76,7 +76,8 @@ void spp_free_ctx(spp_ctx* ctx);
 /* Deterministic trusted setup on the GPU from a 32-byte seed: writes pk ("SPPK") and vk (gnark raw layout). */
 int spp_setup(spp_ctx* ctx, const char* circuit_path, const uint8_t seed[32], const char* pk_path, const char* vk_path);
 
-/* Loads R1CS + proving key, builds the window tables (window_bits in [4,16]; 0 = default 10) in HBM. */
+/* Loads R1CS + proving key, builds the window tables in HBM. window_bits in [4,16], or 0 = the widest window whose
+ * tables fit env SPP_TABLE_BUDGET_GB (default 170) and 75 % of the free HBM. */
 int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const char* pk_path, int window_bits, spp_circuit** out);
 void spp_free_circuit(spp_circuit* c);
 /* info[0..7] = id, n_public (without the constant), n_secret, n_wires, n_constraints, domain_log, n_inputs, window_bits */

@@ -396,8 +396,7 @@ static void merge_point(std::vector<uint32_t>& wires, std::vector<Affine<F>>& pt
 
 extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const char* pk_path, int window_bits, spp_circuit** out) {
   if (!ctx || !circuit_path || !pk_path || !out) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
-  if (window_bits == 0) window_bits = 10;
-  if (window_bits < 4 || window_bits > 16) return fail(SPP_ERR_BAD_INPUT, "window_bits %d outside [4,16]", window_bits);
+  if (window_bits != 0 && (window_bits < 4 || window_bits > 16)) return fail(SPP_ERR_BAD_INPUT, "window_bits %d outside [4,16]", window_bits);
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_TRY(hipSetDevice(ctx->device));
   spp_circuit* c = new spp_circuit();
@@ -412,6 +411,24 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
   if (pk.circuit_id != circ.id || pk.n_wires != circ.n_wires || pk.domain_log != circ.domain_log) {
     delete c;
     return fail(SPP_ERR_FORMAT, "proving key does not match the circuit");
+  }
+  if (window_bits == 0) {
+    // auto: the widest window whose tables fit the budget (SPP_TABLE_BUDGET_GB, default 170, capped at 75 % of the
+    // free HBM): every extra window bit removes ~8 % of the mixed additions of every proof and doubles the tables
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    double budget = 170e9;
+    if (const char* env = getenv("SPP_TABLE_BUDGET_GB")) budget = atof(env) * 1e9;
+    budget = std::min(budget, 0.75 * (double)free_b);
+    const double n1 = (double)(pk.A.size() + pk.B1.size() + pk.K.size() + pk.Z.size() + pk.CB.size() + pk.CS.size() + 3);
+    const double n2 = (double)(pk.B2.size() + 1);
+    int best = 4;
+    for (int cb = 4; cb <= 14; cb++) {
+      double bytes = (n1 * 64.0 + n2 * 128.0) * msm_windows((uint32_t)cb) * (double)(1u << (cb - 1));
+      if (bytes <= budget) best = cb;
+    }
+    window_bits = best;
+    c->c_bits = (uint32_t)best;
   }
   c->logn = circ.domain_log;
   c->n = 1u << c->logn;

@@ -139,11 +139,13 @@ def test_unsatisfied_inputs_are_refused(withdraw_handle, withdraw_kat):
 
 
 def test_odd_batch_sizes_and_default_window(ctx, withdraw_artifacts, withdraw_kat):
-    """P = 1, 3, 70 (not multiples of the wavefront) and the default 10-bit window tables."""
+    """P = 1, 3, 70 (not multiples of the wavefront) and automatically sized window tables (budget 20 GB -> c = 9)."""
     from oracle import native
+    os.environ["SPP_TABLE_BUDGET_GB"] = "20"
     h = ctx.load_circuit(withdraw_artifacts["sppc"], withdraw_artifacts["pk"], 0)
+    del os.environ["SPP_TABLE_BUDGET_GB"]
     try:
-        assert h.window_bits == 10
+        assert h.window_bits == 9 and h.table_bytes <= 20e9
         orc = native.Prover(withdraw_artifacts["sppc"], withdraw_artifacts["pk"])
         rows = _withdraw_variants(withdraw_kat, 4)
         for count in (1, 3, 70):
