@@ -148,6 +148,13 @@ int spp_ntt_fr(spp_ctx* ctx, uint8_t* data, uint32_t logn, int inverse);
 /* sum_i scalars[i] * bases[i]; bases 64 B, scalars 32 B (big-endian); out 64 B. Table-based path. */
 int spp_msm_g1(spp_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, int window_bits, uint8_t out[64]);
 
+/* General-base Pippenger (16-bit signed windows, bucket sort + accumulate + reduce) for large n; same conventions. */
+int spp_msm_g1_pippenger(spp_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[64]);
+/* Synthetic, device-resident form of the same MSM (BASELINE.json configs[4]: n = 2^24): bases k_i*G and scalars from
+ * an LCG of `seed`; scale_be (optional) multiplies every scalar (linearity checks). Mean ms over `iters` runs. */
+int spp_msm_g1_pippenger_bench(spp_ctx* ctx, size_t n, uint64_t seed, const uint8_t scale_be[32], int iters, uint8_t out[64],
+                               float* ms_total, float* ms_bucket_kernel);
+
 #ifdef __cplusplus
 }
 #endif

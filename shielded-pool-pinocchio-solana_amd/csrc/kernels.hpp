@@ -85,6 +85,12 @@ void launch_msm_reduce(hipStream_t st, const XYZZ<F>* partial, XYZZ<F>* out, uin
 uint32_t msm_windows(uint32_t c);
 uint32_t msm_slices(uint32_t N, uint32_t P);
 
+// ---- general-base Pippenger (kernels_pippenger.hip) ----
+size_t pippenger_workspace_bytes(uint32_t n);
+uint32_t pippenger_windows();
+void launch_pippenger_g1(hipStream_t st, const G1Affine* bases, const Fr* scalars, uint32_t n, void* workspace, G1XYZZ** out_windows,
+                         hipEvent_t ev0, hipEvent_t ev1);
+
 // ---- commitment challenge, proof assembly ----
 void launch_challenge(hipStream_t st, const G1XYZZ* commit, Fr* W, uint32_t challenge_wire, uint32_t P, G1Affine* commit_affine,
                       uint32_t* status);

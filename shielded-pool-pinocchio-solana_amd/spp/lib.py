@@ -67,6 +67,8 @@ def load_library():
     L.spp_poseidon2_sponge_batch.argtypes = [vp, sz, u32, cp, vp]
     L.spp_ntt_fr.argtypes = [vp, vp, u32, i32]
     L.spp_msm_g1.argtypes = [vp, cp, cp, sz, i32, vp]
+    L.spp_msm_g1_pippenger.argtypes = [vp, cp, cp, sz, vp]
+    L.spp_msm_g1_pippenger_bench.argtypes = [vp, sz, ctypes.c_uint64, cp, i32, vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     _LIB = L
     return L
 

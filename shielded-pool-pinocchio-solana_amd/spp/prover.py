@@ -49,6 +49,20 @@ class Context:
         check(self.L.spp_msm_g1(self.h, bases_bytes, sc, n, int(window_bits), ctypes.cast(out, ctypes.c_void_p)))
         return out.raw
 
+    def msm_g1_pippenger(self, bases_bytes, scalars):
+        out = ctypes.create_string_buffer(64)
+        sc = b"".join(int(s).to_bytes(32, "big") for s in scalars)
+        check(self.L.spp_msm_g1_pippenger(self.h, bases_bytes, sc, len(scalars), ctypes.cast(out, ctypes.c_void_p)))
+        return out.raw
+
+    def msm_g1_pippenger_bench(self, n, seed=5, scale=None, iters=1):
+        """Returns (result bytes, ms per MSM, ms of the bucket kernel)."""
+        out = ctypes.create_string_buffer(64)
+        t, k = ctypes.c_float(0), ctypes.c_float(0)
+        sb = None if scale is None else int(scale).to_bytes(32, "big")
+        check(self.L.spp_msm_g1_pippenger_bench(self.h, n, seed, sb, iters, ctypes.cast(out, ctypes.c_void_p), ctypes.byref(t), ctypes.byref(k)))
+        return out.raw, t.value, k.value
+
 
 class CircuitHandle:
     def __init__(self, ctx, circuit_path, pk_path, window_bits=0):

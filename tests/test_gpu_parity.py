@@ -284,3 +284,53 @@ def test_poseidon2_sponge_kernel(ctx, rlwe_pk):
     for n in (1, 2, 3, 4):                                       # ragged absorb lengths
         row = [rng.randrange(R) for _ in range(n)]
         assert witness.ct_commitments(ctx, [row]) == [H.poseidon2_sponge(row)]
+
+
+# ---------------------------------------------------------------------------------------------- general Pippenger
+def test_pippenger_matches_oracle_and_is_linear(ctx):
+    from oracle import bn254 as B, native
+    import ctypes
+    rng = random.Random(21)
+    pts = []
+    p = B.G1_GEN
+    for i in range(300):
+        p = B.g1_add(p, B.g1_mul(B.G1_GEN, rng.randrange(1, 1 << 64)))
+        pts.append(p)
+    bases = b"".join(B.g1_to_bytes(q) for q in pts)
+    for n in (0, 1, 2, 300):
+        sc = [rng.randrange(B.R) for _ in range(n)]
+        if n == 300:
+            sc[:8] = [0, 1, B.R - 1, (B.R - 1) // 2, (B.R + 1) // 2, 0x8000, 0x8001, 0xffff]     # window-boundary digits
+            sc[8:40] = [5] * 32                                                                 # one crowded bucket
+        got = ctx.msm_g1_pippenger(bases[:64 * n], sc)
+        out = ctypes.create_string_buffer(64)
+        native.lib().orc_msm_g1(bases[:64 * n], b"".join(s.to_bytes(32, "big") for s in sc), n, ctypes.cast(out, ctypes.c_void_p))
+        assert got == out.raw, n
+        assert got == ctx.msm_g1(bases[:64 * n], sc, 6)                  # table path agrees with the bucket path
+    # size-independent property at a size the oracle cannot check: MSM(k * s) == k * MSM(s)  (2^18 synthetic points)
+    r1, ms, _ = ctx.msm_g1_pippenger_bench(1 << 18, seed=5)
+    k = 0x1234567
+    r2, _, _ = ctx.msm_g1_pippenger_bench(1 << 18, seed=5, scale=k)
+    assert B.g1_to_bytes(B.g1_mul(B.g1_from_bytes(r1), k)) == r2
+    # and against the oracle on a 2^12 prefix-sized instance of the same generator
+    r3, _, _ = ctx.msm_g1_pippenger_bench(1 << 12, seed=9)
+    x = (9 * 6364136223846793005 + 1442695040888963407) % (1 << 64)
+    def nxt():
+        nonlocal x
+        x = (x * 6364136223846793005 + 1442695040888963407) % (1 << 64)
+        return x
+    ks, ss = [], []
+    for _ in range(1 << 12):
+        ks.append(nxt() | 1)
+        w = []
+        for _ in range(4):
+            v = nxt(); w += [v & 0xffffffff, v >> 32]
+        w[7] &= 0x1fffffff
+        ss.append(sum(l << (32 * i) for i, l in enumerate(w)))
+    # the generator writes raw limbs into Montgomery storage: the field element is limbs * 2^-256
+    rinv = pow(1 << 256, -1, B.R)
+    ss = [s * rinv % B.R for s in ss]
+    out = ctypes.create_string_buffer(64)
+    basesb = b"".join(B.g1_to_bytes(B.g1_mul(B.G1_GEN, kk)) for kk in ks)
+    native.lib().orc_msm_g1(basesb, b"".join(s.to_bytes(32, "big") for s in ss), 1 << 12, ctypes.cast(out, ctypes.c_void_p))
+    assert r3 == out.raw
