@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="proofs per GPU per step")
+    ap.add_argument("--batch", type=int, default=0, help="proofs per GPU per step (0 = 1024 for withdraw, 256 for audit)")
     ap.add_argument("--circuit", default=os.environ.get("SPP_BENCH_CIRCUIT", "withdraw"), choices=["withdraw", "audit"])
     ap.add_argument("--window", type=int, default=int(os.environ.get("SPP_WINDOW", "0")), help="MSM window bits; 0 = auto (largest tables within the HBM budget)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -221,12 +221,13 @@ def main():
         torch.cuda.empty_cache()
         return out
 
-    main_res = run_circuit(args.circuit, args.batch, args.steps, args.warmup, not args.no_cpu_baseline)
+    default_batch = {"withdraw": 1024, "audit": 256}
+    main_res = run_circuit(args.circuit, args.batch or default_batch[args.circuit], args.steps, args.warmup, not args.no_cpu_baseline)
     # the other circuit of BASELINE.json's metric, as a secondary figure (single GPU runs only)
     other = None
     if world == 1 and not args.no_secondary:
         oc = "audit" if args.circuit == "withdraw" else "withdraw"
-        other = run_circuit(oc, 128 if oc == "audit" else 256, 3, 1, not args.no_cpu_baseline)
+        other = run_circuit(oc, default_batch[oc], 3, 1, not args.no_cpu_baseline)
     if rank == 0:
         line = {"metric": "Groth16 proofs/sec", "value": main_res["value"], "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
