@@ -73,8 +73,12 @@ void launch_scale_rows(hipStream_t st, Fr* data, const Fr* table, uint32_t n, ui
 void launch_qap_pointwise(hipStream_t st, Fr* abc, uint32_t n, uint32_t P, Fr zinv);
 
 // ---- MSM with precomputed window tables ----
+// builds rows [row0, row0 + nrows) (row = base * windows + window; row0 a multiple of 64) of the table of N bases;
+// tmp / tmp_pre: nrows * 2^(c-1) elements each.  Layout: see kernels_msm.hip.
 template <class F>
-void launch_build_table(hipStream_t st, const Affine<F>* bases, uint32_t N, uint32_t c, Affine<F>* table, XYZZ<F>* tmp, F* tmp_pre);
+void launch_build_table(hipStream_t st, const Affine<F>* bases, uint32_t N, uint32_t c, uint32_t row0, uint32_t nrows, Affine<F>* table,
+                        XYZZ<F>* tmp, F* tmp_pre);
+size_t msm_table_elems(uint32_t N, uint32_t c);
 // lane g -> (slice g / P, proof g % P); partial[S][P]
 template <class F>
 void launch_msm_accumulate(hipStream_t st, const Affine<F>* table, const uint32_t* rows, const Fr* scalars, XYZZ<F>* partial, uint32_t N,

@@ -31,22 +31,30 @@ uint32_t msm_slices(uint32_t N, uint32_t P) {
 }
 
 // ----------------------------------------------------------------------------------------------------
-// table construction: one lane per (base, window) row
+// table construction: one lane per (base, window) row.
+// Table layout: rows are grouped in blocks of 64; entry d of row `row` lives at ((row/64)*E + d)*64 + row%64, so the
+// 64 lanes of a wave that build 64 consecutive rows write 64 consecutive points (coalesced 4 KiB per step), and so do
+// the XYZZ temporaries.  The MSM kernels gather single entries at random d anyway, so they lose nothing.
 // ----------------------------------------------------------------------------------------------------
 template <class F>
 __global__ void __launch_bounds__(64) k_build_table(const Affine<F>* __restrict__ bases, uint32_t N, uint32_t c, uint32_t Wn,
-                                                    Affine<F>* __restrict__ table, XYZZ<F>* __restrict__ tmp,
-                                                    F* __restrict__ tmp_pre) {
-  const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= N * Wn) return;
-  const uint32_t i = row / Wn, j = row % Wn;
+                                                    uint32_t row0, uint32_t nrows, Affine<F>* __restrict__ table,
+                                                    XYZZ<F>* __restrict__ tmp, F* __restrict__ tmp_pre) {
+  const uint32_t rl = blockIdx.x * blockDim.x + threadIdx.x;   // row within this launch (row0 is a multiple of 64)
+  if (rl >= nrows) return;
+  const uint32_t row = row0 + rl;
   const uint32_t E = 1u << (c - 1);
-  Affine<F>* out = table + (size_t)row * E;
-  XYZZ<F>* t = tmp + (size_t)row * E;
-  F* pre = tmp_pre + (size_t)row * E;
+  Affine<F>* out = table + ((size_t)(row >> 6) * E) * 64 + (row & 63);   // entry d at out[d * 64]
+  XYZZ<F>* t = tmp + rl;                                                  // entry d at t[d * nrows]
+  F* pre = tmp_pre + rl;
+  if (row >= N * Wn) {   // padding rows of the last block
+    for (uint32_t d = 0; d < E; d++) out[(size_t)d * 64] = Affine<F>::infinity();
+    return;
+  }
+  const uint32_t i = row / Wn, j = row % Wn;
   Affine<F> base = bases[i];
   if (base.is_inf()) {
-    for (uint32_t d = 0; d < E; d++) out[d] = Affine<F>::infinity();
+    for (uint32_t d = 0; d < E; d++) out[(size_t)d * 64] = Affine<F>::infinity();
     return;
   }
   XYZZ<F> b = XYZZ<F>::from_affine(base);
@@ -55,30 +63,38 @@ __global__ void __launch_bounds__(64) k_build_table(const Affine<F>* __restrict_
   XYZZ<F> acc = XYZZ<F>::from_affine(bj);
   F prod = F::one();
   for (uint32_t d = 0; d < E; d++) {
-    t[d] = acc;
-    pre[d] = prod;
+    t[(size_t)d * nrows] = acc;
+    pre[(size_t)d * nrows] = prod;
     prod = prod * (acc.ZZ * acc.ZZZ);
     acc.madd(bj);
   }
   F inv = prod.inv();
   for (uint32_t d = E; d-- > 0;) {
-    XYZZ<F> q = t[d];
-    F I = inv * pre[d];
+    XYZZ<F> q = t[(size_t)d * nrows];
+    F I = inv * pre[(size_t)d * nrows];
     inv = inv * (q.ZZ * q.ZZZ);
     F izz = I * q.ZZZ;
     F izzz = I * q.ZZ;
-    out[d] = {q.X * izz, q.Y * izzz};
+    out[(size_t)d * 64] = {q.X * izz, q.Y * izzz};
   }
 }
 
-template <class F>
-void launch_build_table(hipStream_t st, const Affine<F>* bases, uint32_t N, uint32_t c, Affine<F>* table, XYZZ<F>* tmp, F* tmp_pre) {
-  uint32_t rows = N * msm_windows(c);
-  if (rows == 0) return;
-  hipLaunchKernelGGL(k_build_table<F>, dim3((rows + 63) / 64), dim3(64), 0, st, bases, N, c, msm_windows(c), table, tmp, tmp_pre);
+// number of table elements (points) for N bases at window c, including the padding of the last 64-row block
+size_t msm_table_elems(uint32_t N, uint32_t c) {
+  size_t rows = (size_t)N * msm_windows(c);
+  return ((rows + 63) / 64) * 64 * ((size_t)1 << (c - 1));
 }
-template void launch_build_table<Fq>(hipStream_t, const Affine<Fq>*, uint32_t, uint32_t, Affine<Fq>*, XYZZ<Fq>*, Fq*);
-template void launch_build_table<Fq2>(hipStream_t, const Affine<Fq2>*, uint32_t, uint32_t, Affine<Fq2>*, XYZZ<Fq2>*, Fq2*);
+
+template <class F>
+void launch_build_table(hipStream_t st, const Affine<F>* bases, uint32_t N, uint32_t c, uint32_t row0, uint32_t nrows, Affine<F>* table,
+                        XYZZ<F>* tmp, F* tmp_pre) {
+  if (nrows == 0) return;
+  hipLaunchKernelGGL(k_build_table<F>, dim3((nrows + 63) / 64), dim3(64), 0, st, bases, N, c, msm_windows(c), row0, nrows, table, tmp,
+                     tmp_pre);
+}
+template void launch_build_table<Fq>(hipStream_t, const Affine<Fq>*, uint32_t, uint32_t, uint32_t, uint32_t, Affine<Fq>*, XYZZ<Fq>*, Fq*);
+template void launch_build_table<Fq2>(hipStream_t, const Affine<Fq2>*, uint32_t, uint32_t, uint32_t, uint32_t, Affine<Fq2>*, XYZZ<Fq2>*,
+                                      Fq2*);
 
 // ----------------------------------------------------------------------------------------------------
 // signed-window recoding helpers (scalar in canonical limbs, magnitude < 2^253 after sign folding)
@@ -140,14 +156,14 @@ __global__ void __launch_bounds__(256) k_msm_fixed(const Affine<F>* __restrict__
     if (s.is_zero()) continue;
     Recoder rc;
     rc.init(s);
-    const Affine<F>* trow = table + (size_t)i * Wn * E;
+    uint32_t row = i * Wn;
 #pragma unroll 1
-    for (uint32_t j = 0; j < Wn; j++) {
+    for (uint32_t j = 0; j < Wn; j++, row++) {
       if (rc.rest_is_zero()) break;
       bool sgn;
       uint32_t d = rc.next(c, sgn);
       if (d != 0) {
-        Affine<F> e = trow[(size_t)j * E + (d - 1)];
+        Affine<F> e = table[((size_t)(row >> 6) * E + (d - 1)) * 64 + (row & 63)];
         if (sgn) e.y = e.y.neg();
         acc.madd(e);
       }
@@ -216,7 +232,7 @@ __global__ void __launch_bounds__(64) k_fixed_base_mul(const Affine<F>* __restri
       bool sgn;
       uint32_t d = rc.next(c, sgn);
       if (d != 0) {
-        Affine<F> e = gen_table[(size_t)j * E + (d - 1)];
+        Affine<F> e = gen_table[((size_t)(j >> 6) * E + (d - 1)) * 64 + (j & 63)];
         if (sgn) e.y = e.y.neg();
         acc.madd(e);
       }

@@ -219,32 +219,39 @@ static int upload_sparse(spp_circuit* c, const Circuit& circ, const Sparse& m, D
   return 0;
 }
 
-// builds the window table of `pts` on the device in chunks bounded by ~1.5 GiB of temporaries
+// window tables: allocate first (all sets), then build with temporaries sized from the HBM that is left, so that
+// each launch has enough rows (>= tens of thousands of lanes) to fill the chip
 template <class F>
-static int build_table_chunked(spp_circuit* c, const std::vector<Affine<F>>& pts, uint32_t cbits, Affine<F>** table_out) {
-  hipStream_t st = c->ctx->stream;
-  const uint32_t Wn = msm_windows(cbits), E = 1u << (cbits - 1);
-  const size_t N = pts.size();
-  size_t table_elems = std::max<size_t>(N * Wn * E, 1);
+static int alloc_table(spp_circuit* c, size_t N, uint32_t cbits, Affine<F>** table_out) {
+  size_t table_elems = std::max<size_t>(msm_table_elems((uint32_t)N, cbits), 1);
   Affine<F>* table;
   HIP_TRY(hipMalloc((void**)&table, table_elems * sizeof(Affine<F>)));
   c->owned.push_back(table);
   c->table_bytes += table_elems * sizeof(Affine<F>);
   *table_out = table;
+  return 0;
+}
+template <class F>
+static int build_table(spp_circuit* c, const std::vector<Affine<F>>& pts, uint32_t cbits, Affine<F>* table, size_t temp_budget) {
+  hipStream_t st = c->ctx->stream;
+  const uint32_t Wn = msm_windows(cbits), E = 1u << (cbits - 1);
+  const size_t N = pts.size();
   if (N == 0) return 0;
-  const size_t per_base = (size_t)Wn * E * (sizeof(XYZZ<F>) + sizeof(F));
-  size_t chunk = std::max<size_t>(1, ((size_t)3 << 29) / per_base);
-  chunk = std::min(chunk, N);
+  const size_t rows_total = ((N * Wn + 63) / 64) * 64;
+  const size_t per_row = (size_t)E * (sizeof(XYZZ<F>) + sizeof(F));
+  size_t chunk = std::max<size_t>(64, ((temp_budget / per_row) / 64) * 64);
+  chunk = std::min(chunk, (size_t)65536);   // larger launches only add TLB misses (the d-stride is chunk * 128 B)
+  chunk = std::min(chunk, rows_total);
   Affine<F>* d_bases;
   XYZZ<F>* tmp;
   F* tmp_pre;
   HIP_TRY(hipMalloc((void**)&d_bases, N * sizeof(Affine<F>)));
   HIP_TRY(hipMemcpy(d_bases, pts.data(), N * sizeof(Affine<F>), hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc((void**)&tmp, chunk * Wn * E * sizeof(XYZZ<F>)));
-  HIP_TRY(hipMalloc((void**)&tmp_pre, chunk * Wn * E * sizeof(F)));
-  for (size_t i0 = 0; i0 < N; i0 += chunk) {
-    uint32_t cnt = (uint32_t)std::min(chunk, N - i0);
-    launch_build_table<F>(st, d_bases + i0, cnt, cbits, table + i0 * Wn * E, tmp, tmp_pre);
+  HIP_TRY(hipMalloc((void**)&tmp, chunk * E * sizeof(XYZZ<F>)));
+  HIP_TRY(hipMalloc((void**)&tmp_pre, chunk * E * sizeof(F)));
+  for (size_t r0 = 0; r0 < rows_total; r0 += chunk) {
+    uint32_t cnt = (uint32_t)std::min(chunk, rows_total - r0);
+    launch_build_table<F>(st, d_bases, (uint32_t)N, cbits, (uint32_t)r0, cnt, table, tmp, tmp_pre);
   }
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipGetLastError());
@@ -253,13 +260,46 @@ static int build_table_chunked(spp_circuit* c, const std::vector<Affine<F>>& pts
   hipFree(tmp_pre);
   return 0;
 }
+static size_t table_temp_budget() {
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return (size_t)2 << 30;
+  size_t b = free_b / 2;                       // leave room for the batch workspaces
+  b = std::min(b, (size_t)48 << 30);
+  return std::max(b, (size_t)1 << 28);
+}
+template <class F>
+static int build_table_chunked(spp_circuit* c, const std::vector<Affine<F>>& pts, uint32_t cbits, Affine<F>** table_out) {
+  if (int e = alloc_table<F>(c, pts.size(), cbits, table_out)) return e;
+  return build_table<F>(c, pts, cbits, *table_out, std::min(table_temp_budget(), (size_t)2 << 30));
+}
+
+template <class F>
+struct PendingTable {
+  std::vector<Affine<F>> pts;
+  Affine<F>* table;
+};
+static std::vector<PendingTable<Fq>> g_pending1;    // guarded by ctx->mu (spp_load_circuit holds it)
+static std::vector<PendingTable<Fq2>> g_pending2;
+static std::vector<PendingTable<Fq>>& pending(Fq*) { return g_pending1; }
+static std::vector<PendingTable<Fq2>>& pending(Fq2*) { return g_pending2; }
 
 template <class F>
 static int make_set(spp_circuit* c, MsmSet<F>* set, const std::vector<uint32_t>& rows, const std::vector<Affine<F>>& pts, bool from_h) {
   set->N = (uint32_t)pts.size();
   set->from_h = from_h;
   if (int e = own_upload(c, &set->rows, rows)) return e;
-  return build_table_chunked<F>(c, pts, c->c_bits, &set->table);
+  if (int e = alloc_table<F>(c, pts.size(), c->c_bits, &set->table)) return e;
+  pending((F*)nullptr).push_back({pts, set->table});
+  return 0;
+}
+static int build_pending(spp_circuit* c) {
+  const size_t budget = table_temp_budget();
+  int e = 0;
+  for (auto& p : g_pending1) if (!e) e = build_table<Fq>(c, p.pts, c->c_bits, p.table, budget);
+  for (auto& p : g_pending2) if (!e) e = build_table<Fq2>(c, p.pts, c->c_bits, p.table, budget);
+  g_pending1.clear();
+  g_pending2.clear();
+  return e;
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -593,6 +633,7 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
   }
   if ((e = make_set(c, &c->CB, pk.CB_w, pk.CB, false))) return e;
   if ((e = make_set(c, &c->CS, pk.CS_w, pk.CS, false))) return e;
+  if ((e = build_pending(c))) return e;
 
   for (int k = 0; k < 2; k++) {
     Workspace& w = c->ws[k];
@@ -983,15 +1024,16 @@ extern "C" int spp_setup(spp_ctx* ctx, const char* circuit_path, const uint8_t s
   Fr *d_s1, *d_s2;
   HIP_TRY(hipMalloc((void**)&d_g1, sizeof g1)); HIP_TRY(hipMemcpy(d_g1, &g1, sizeof g1, hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc((void**)&d_g2, sizeof g2)); HIP_TRY(hipMemcpy(d_g2, &g2, sizeof g2, hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc((void**)&t1, sizeof(G1Affine) * Wn * E)); HIP_TRY(hipMalloc((void**)&t2, sizeof(G2Affine) * Wn * E));
-  HIP_TRY(hipMalloc((void**)&tmp1, sizeof(G1XYZZ) * Wn * E)); HIP_TRY(hipMalloc((void**)&tmp2, sizeof(G2XYZZ) * Wn * E));
-  HIP_TRY(hipMalloc((void**)&pre1, sizeof(Fq) * Wn * E)); HIP_TRY(hipMalloc((void**)&pre2, sizeof(Fq2) * Wn * E));
+  const size_t ge = msm_table_elems(1, cb), gr = ((size_t)Wn + 63) / 64 * 64;
+  HIP_TRY(hipMalloc((void**)&t1, sizeof(G1Affine) * ge)); HIP_TRY(hipMalloc((void**)&t2, sizeof(G2Affine) * ge));
+  HIP_TRY(hipMalloc((void**)&tmp1, sizeof(G1XYZZ) * gr * E)); HIP_TRY(hipMalloc((void**)&tmp2, sizeof(G2XYZZ) * gr * E));
+  HIP_TRY(hipMalloc((void**)&pre1, sizeof(Fq) * gr * E)); HIP_TRY(hipMalloc((void**)&pre2, sizeof(Fq2) * gr * E));
   HIP_TRY(hipMalloc((void**)&d_s1, sizeof(Fr) * s1.size())); HIP_TRY(hipMalloc((void**)&d_s2, sizeof(Fr) * s2.size()));
   HIP_TRY(hipMalloc((void**)&o1, sizeof(G1Affine) * s1.size())); HIP_TRY(hipMalloc((void**)&o2, sizeof(G2Affine) * s2.size()));
   HIP_TRY(hipMemcpyAsync(d_s1, s1.data(), sizeof(Fr) * s1.size(), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(d_s2, s2.data(), sizeof(Fr) * s2.size(), hipMemcpyHostToDevice, st));
-  launch_build_table<Fq>(st, d_g1, 1, cb, t1, tmp1, pre1);
-  launch_build_table<Fq2>(st, d_g2, 1, cb, t2, tmp2, pre2);
+  launch_build_table<Fq>(st, d_g1, 1, cb, 0, (uint32_t)gr, t1, tmp1, pre1);
+  launch_build_table<Fq2>(st, d_g2, 1, cb, 0, (uint32_t)gr, t2, tmp2, pre2);
   launch_fixed_base_mul<Fq>(st, t1, cb, d_s1, (uint32_t)s1.size(), o1, nullptr);
   launch_fixed_base_mul<Fq2>(st, t2, cb, d_s2, (uint32_t)s2.size(), o2, nullptr);
   std::vector<G1Affine> p1(s1.size());
@@ -1097,7 +1139,8 @@ extern "C" int spp_msm_g1(spp_ctx* ctx, const uint8_t* bases, const uint8_t* sca
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const uint32_t cb = (uint32_t)window_bits, Wn = msm_windows(cb), E = 1u << (cb - 1);
-  if ((uint64_t)n * Wn * E * 64 > ((uint64_t)64 << 30)) return fail(SPP_ERR_BAD_INPUT, "table would exceed 64 GiB; use a smaller window");
+  (void)E;
+  if ((uint64_t)msm_table_elems((uint32_t)n, cb) * 64 > ((uint64_t)64 << 30)) return fail(SPP_ERR_BAD_INPUT, "table would exceed 64 GiB; use a smaller window");
   std::vector<G1Affine> pts(n);
   std::vector<Fr> sc(n);
   std::vector<uint32_t> rows(n);
@@ -1434,10 +1477,11 @@ extern "C" int spp_msm_g1_pippenger_bench(spp_ctx* ctx, size_t n, uint64_t seed,
   const uint32_t cb = 8, Wn = msm_windows(cb), E = 1u << (cb - 1);
   G1Affine g1{Fq::from_u64(1), Fq::from_u64(2)};
   UP(dg, &g1, sizeof g1);
-  HIP_TRY(dt.alloc(sizeof(G1Affine) * Wn * E));
-  HIP_TRY(dtmp.alloc(sizeof(G1XYZZ) * Wn * E));
-  HIP_TRY(dpre.alloc(sizeof(Fq) * Wn * E));
-  launch_build_table<Fq>(st, dg.as<G1Affine>(), 1, cb, dt.as<G1Affine>(), dtmp.as<G1XYZZ>(), dpre.as<Fq>());
+  const size_t gr = ((size_t)Wn + 63) / 64 * 64;
+  HIP_TRY(dt.alloc(sizeof(G1Affine) * msm_table_elems(1, cb)));
+  HIP_TRY(dtmp.alloc(sizeof(G1XYZZ) * gr * E));
+  HIP_TRY(dpre.alloc(sizeof(Fq) * gr * E));
+  launch_build_table<Fq>(st, dg.as<G1Affine>(), 1, cb, 0, (uint32_t)gr, dt.as<G1Affine>(), dtmp.as<G1XYZZ>(), dpre.as<Fq>());
   launch_fixed_base_mul<Fq>(st, dt.as<G1Affine>(), cb, dk.as<Fr>(), (uint32_t)n, dp.as<G1Affine>(), nullptr);
   HIP_TRY(hipStreamSynchronize(st));
   hipEvent_t e0, e1, k0, k1;
