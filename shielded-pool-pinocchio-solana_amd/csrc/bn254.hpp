@@ -345,15 +345,61 @@ struct Fq2 {
   friend SPP_HD Fq2 operator-(const Fq2& a, const Fq2& b) { return {a.c0 - b.c0, a.c1 - b.c1}; }
   SPP_HD Fq2 neg() const { return {c0.neg(), c1.neg()}; }
   SPP_HD Fq2 dbl() const { return {c0.dbl(), c1.dbl()}; }
+  // Lazy reduction on the 29-bit column form of Fq (see Fp::operator*): both components are sums of two products,
+  // accumulated as 162 v_mad_u64_u32 into the same 17 columns (2 * 9 * 2^58 + reduction < 2^63) and reduced ONCE
+  // each -- two Montgomery reductions instead of three multiplications' worth, and no intermediate add/sub.
+  //   c0 = a0*b0 + a1*(-b1),  c1 = a0*b1 + a1*b0
   friend SPP_HD Fq2 operator*(const Fq2& a, const Fq2& b) {
-    Fq v0 = a.c0 * b.c0;
-    Fq v1 = a.c1 * b.c1;
-    Fq s = (a.c0 + a.c1) * (b.c0 + b.c1);
-    return {v0 - v1, s - v0 - v1};
+    uint32_t a0[9], a1[9], b0[9], b1[9], n1[9];
+    Fq::to9(a.c0.l, a0);
+    Fq::to9(a.c1.l, a1);
+    Fq::to9(b.c0.l, b0);
+    Fq::to9(b.c1.l, b1);
+    const Fq nb1 = b.c1.neg();
+    Fq::to9(nb1.l, n1);
+    uint64_t c[18];
+    SPP_UNROLL for (int k = 0; k < 18; k++) c[k] = 0;
+    SPP_UNROLL for (int i = 0; i < 9; i++) {
+      SPP_UNROLL for (int j = 0; j < 9; j++) {
+        c[i + j] += (uint64_t)a0[i] * b0[j];
+        c[i + j] += (uint64_t)a1[i] * n1[j];
+      }
+    }
+    Fq2 r;
+    r.c0 = Fq::reduce_columns(c);
+    SPP_UNROLL for (int k = 0; k < 18; k++) c[k] = 0;
+    SPP_UNROLL for (int i = 0; i < 9; i++) {
+      SPP_UNROLL for (int j = 0; j < 9; j++) {
+        c[i + j] += (uint64_t)a0[i] * b1[j];
+        c[i + j] += (uint64_t)a1[i] * b0[j];
+      }
+    }
+    r.c1 = Fq::reduce_columns(c);
+    return r;
   }
+  //   c0 = a0^2 + a1*(-a1),  c1 = (2 a0) * a1
   SPP_HD Fq2 sqr() const {
-    Fq t = c0 * c1;
-    return {(c0 + c1) * (c0 - c1), t.dbl()};
+    uint32_t a0[9], a1[9], n1[9], d0[9];
+    Fq::to9(c0.l, a0);
+    Fq::to9(c1.l, a1);
+    const Fq na1 = c1.neg();
+    Fq::to9(na1.l, n1);
+    SPP_UNROLL for (int i = 0; i < 9; i++) d0[i] = a0[i] << 1;
+    uint64_t c[18];
+    SPP_UNROLL for (int k = 0; k < 18; k++) c[k] = 0;
+    SPP_UNROLL for (int i = 0; i < 9; i++) {
+      c[2 * i] += (uint64_t)a0[i] * a0[i];
+      SPP_UNROLL for (int j = i + 1; j < 9; j++) c[i + j] += (uint64_t)a0[i] * d0[j];
+      SPP_UNROLL for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)a1[i] * n1[j];
+    }
+    Fq2 r;
+    r.c0 = Fq::reduce_columns(c);
+    SPP_UNROLL for (int k = 0; k < 18; k++) c[k] = 0;
+    SPP_UNROLL for (int i = 0; i < 9; i++) {
+      SPP_UNROLL for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)d0[i] * a1[j];
+    }
+    r.c1 = Fq::reduce_columns(c);
+    return r;
   }
   SPP_HD Fq2 inv() const {
     Fq d = (c0.sqr() + c1.sqr()).inv();
