@@ -190,7 +190,7 @@ def main():
                 "config": {"workload": "%s, batch of %d independent proofs per GPU per step" % (
                     "noir_circuit withdraw (Poseidon Merkle depth 16 + Grumpkin)" if circuit == "withdraw" else "audit_circuit (RLWE, const-PK)", B),
                     "circuit": circuit, "n_constraints": h.n_constraints, "n_wires": h.n_wires, "domain": 1 << h.domain_log,
-                    "batch_per_gpu": B, "window_bits": h.window_bits, "msm_sizes": dict(zip(["A", "B1", "K", "Z", "CB", "CS", "B2(G2)"], sizes)),
+                    "batch_per_gpu": B, "window_bits": h.window_bits, "msm_windows": dict(zip(["A", "B1", "K", "Z", "CB", "CS", "B2(G2)"], h.msm_windows())), "msm_sizes": dict(zip(["A", "B1", "K", "Z", "CB", "CS", "B2(G2)"], sizes)),
                     "table_bytes": h.table_bytes, "parallelism": "independent proofs x%d" % world,
                     "pk_bcast_ms": round(bcast_ms, 3), "setup_s": round(setup_s, 2), "load_s": round(load_s, 2)},
                 "stage_ms_per_step": {k: round(v / steps, 3) for k, v in zip(

@@ -76,14 +76,16 @@ void spp_free_ctx(spp_ctx* ctx);
 /* Deterministic trusted setup on the GPU from a 32-byte seed: writes pk ("SPPK") and vk (gnark raw layout). */
 int spp_setup(spp_ctx* ctx, const char* circuit_path, const uint8_t seed[32], const char* pk_path, const char* vk_path);
 
-/* Loads R1CS + proving key, builds the window tables in HBM. window_bits in [4,16], or 0 = the widest window whose
- * tables fit env SPP_TABLE_BUDGET_GB (default 170) and 75 % of the free HBM. */
+/* Loads R1CS + proving key, builds the window tables in HBM. window_bits in [4,16] = the same window for every MSM set;
+ * 0 = per-set windows chosen greedily within env SPP_TABLE_BUDGET_GB (default 200) and 75 % of the free HBM. */
 int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const char* pk_path, int window_bits, spp_circuit** out);
 void spp_free_circuit(spp_circuit* c);
 /* info[0..7] = id, n_public (without the constant), n_secret, n_wires, n_constraints, domain_log, n_inputs, window_bits */
 int spp_circuit_info(const spp_circuit* c, uint32_t info[8]);
 /* number of bases per MSM of one proof: G1 sets A, B1, K, Z, commitment basis, commitment basis^sigma; then the G2 set B2 */
 int spp_circuit_msm_sizes(const spp_circuit* c, uint32_t sizes[7]);
+/* window bits of the table of each of those sets (same order) */
+int spp_circuit_msm_windows(const spp_circuit* c, uint32_t bits[7]);
 /* exact bytes of HBM held by the window tables */
 uint64_t spp_circuit_table_bytes(const spp_circuit* c);
 

@@ -148,10 +148,11 @@ __global__ void __launch_bounds__(256) k_msm_fixed(const Affine<F>* __restrict__
   if (g >= S * P) return;
   const uint32_t p = g % P, slice = g / P;
   const uint32_t E = 1u << (c - 1);
-  uint32_t i0 = slice * L, i1 = i0 + L;
-  if (i1 > N) i1 = N;
+  // slice s takes bases s, s+S, s+2S, ...: neighbouring wires have similar scalar sizes (runs of bits, runs of hash
+  // states), so a strided split gives every slice the same mix and the launch no tail of heavy slices
+  (void)L;
   XYZZ<F> acc = XYZZ<F>::infinity();
-  for (uint32_t i = i0; i < i1; i++) {
+  for (uint32_t i = slice; i < N; i += S) {
     Fr s = scalars[(size_t)rows[i] * P + p];
     if (s.is_zero()) continue;
     Recoder rc;

@@ -146,6 +146,7 @@ struct MsmSet {
   Affine<F>* table = nullptr;
   uint32_t* rows = nullptr;
   bool from_h = false;   // scalars come from the h array instead of the witness
+  uint32_t c = 0;        // window bits of this set's table
 };
 template <class F>
 struct MsmBuf {
@@ -277,6 +278,7 @@ template <class F>
 struct PendingTable {
   std::vector<Affine<F>> pts;
   Affine<F>* table;
+  uint32_t c;
 };
 static std::vector<PendingTable<Fq>> g_pending1;    // guarded by ctx->mu (spp_load_circuit holds it)
 static std::vector<PendingTable<Fq2>> g_pending2;
@@ -284,19 +286,21 @@ static std::vector<PendingTable<Fq>>& pending(Fq*) { return g_pending1; }
 static std::vector<PendingTable<Fq2>>& pending(Fq2*) { return g_pending2; }
 
 template <class F>
-static int make_set(spp_circuit* c, MsmSet<F>* set, const std::vector<uint32_t>& rows, const std::vector<Affine<F>>& pts, bool from_h) {
+static int make_set(spp_circuit* c, MsmSet<F>* set, const std::vector<uint32_t>& rows, const std::vector<Affine<F>>& pts, bool from_h,
+                    uint32_t cbits) {
   set->N = (uint32_t)pts.size();
   set->from_h = from_h;
+  set->c = cbits;
   if (int e = own_upload(c, &set->rows, rows)) return e;
-  if (int e = alloc_table<F>(c, pts.size(), c->c_bits, &set->table)) return e;
-  pending((F*)nullptr).push_back({pts, set->table});
+  if (int e = alloc_table<F>(c, pts.size(), cbits, &set->table)) return e;
+  pending((F*)nullptr).push_back({pts, set->table, cbits});
   return 0;
 }
 static int build_pending(spp_circuit* c) {
   const size_t budget = table_temp_budget();
   int e = 0;
-  for (auto& p : g_pending1) if (!e) e = build_table<Fq>(c, p.pts, c->c_bits, p.table, budget);
-  for (auto& p : g_pending2) if (!e) e = build_table<Fq2>(c, p.pts, c->c_bits, p.table, budget);
+  for (auto& p : g_pending1) if (!e) e = build_table<Fq>(c, p.pts, p.c, p.table, budget);
+  for (auto& p : g_pending2) if (!e) e = build_table<Fq2>(c, p.pts, p.c, p.table, budget);
   g_pending1.clear();
   g_pending2.clear();
   return e;
@@ -452,23 +456,46 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
     delete c;
     return fail(SPP_ERR_FORMAT, "proving key does not match the circuit");
   }
-  if (window_bits == 0) {
-    // auto: the widest window whose tables fit the budget (SPP_TABLE_BUDGET_GB, default 170, capped at 75 % of the
-    // free HBM): every extra window bit removes ~8 % of the mixed additions of every proof and doubles the tables
-    size_t free_b = 0, total_b = 0;
-    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    double budget = 170e9;
-    if (const char* env = getenv("SPP_TABLE_BUDGET_GB")) budget = atof(env) * 1e9;
-    budget = std::min(budget, 0.75 * (double)free_b);
-    const double n1 = (double)(pk.A.size() + pk.B1.size() + pk.K.size() + pk.Z.size() + pk.CB.size() + pk.CS.size() + 3);
-    const double n2 = (double)(pk.B2.size() + 1);
-    int best = 4;
-    for (int cb = 4; cb <= 14; cb++) {
-      double bytes = (n1 * 64.0 + n2 * 128.0) * msm_windows((uint32_t)cb) * (double)(1u << (cb - 1));
-      if (bytes <= budget) best = cb;
+  // window bits per MSM set: uniform when requested, otherwise a greedy split of the HBM budget (env
+  // SPP_TABLE_BUDGET_GB, default 200, capped at 75 % of the free HBM): repeatedly widen the set whose next window bit
+  // removes the most mixed-addition work per extra byte (one bit ~ -8 % additions, x2 table; a G2 addition is
+  // weighted 2.7 G1 additions).  The two commitment sets only ever see bytes / small counters: fixed 9-bit windows.
+  uint32_t cw[7];   // A, B1, K, Z, CB, CS, B2
+  {
+    const double nset[7] = {(double)pk.A.size() + 2, (double)pk.B1.size() + 2, (double)pk.K.size() + 1, (double)pk.Z.size(),
+                            (double)pk.CB.size(), (double)pk.CS.size(), (double)pk.B2.size() + 2};
+    const double esz[7] = {64, 64, 64, 64, 64, 64, 128}, wgt[7] = {1, 1, 1, 1, 0, 0, 2.7};
+    auto bytes = [&](int s, int cb) { return nset[s] * esz[s] * msm_windows((uint32_t)cb) * (double)(1u << (cb - 1)); };
+    if (window_bits != 0) {
+      for (int s = 0; s < 7; s++) cw[s] = (uint32_t)window_bits;
+    } else {
+      size_t free_b = 0, total_b = 0;
+      HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+      double budget = 200e9;
+      if (const char* env = getenv("SPP_TABLE_BUDGET_GB")) budget = atof(env) * 1e9;
+      budget = std::min(budget, 0.75 * (double)free_b);
+      int cur[7] = {6, 6, 6, 6, 9, 9, 6};
+      double used = 0;
+      for (int s = 0; s < 7; s++) used += bytes(s, cur[s]);
+      for (;;) {
+        int best = -1;
+        double best_gain = 0;
+        for (int s = 0; s < 7; s++) {
+          if (wgt[s] == 0 || cur[s] >= 15) continue;
+          double extra = bytes(s, cur[s] + 1) - bytes(s, cur[s]);
+          if (used + extra > budget) continue;
+          double saved = wgt[s] * nset[s] * ((double)msm_windows((uint32_t)cur[s]) - (double)msm_windows((uint32_t)cur[s] + 1));
+          double gain = saved / extra;
+          if (saved <= 0) gain = 1e-30;   // a bit that does not change the window count yet may enable the next one
+          if (gain > best_gain) { best_gain = gain; best = s; }
+        }
+        if (best < 0) break;
+        used += bytes(best, cur[best] + 1) - bytes(best, cur[best]);
+        cur[best]++;
+      }
+      for (int s = 0; s < 7; s++) cw[s] = (uint32_t)cur[s];
     }
-    window_bits = best;
-    c->c_bits = (uint32_t)best;
+    c->c_bits = cw[3];   // reported window = that of the largest set (Z)
   }
   c->logn = circ.domain_log;
   c->n = 1u << c->logn;
@@ -596,27 +623,27 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
     std::vector<G1Affine> p = pk.A;
     merge_point(w, p, 0u, pk.alpha1);
     w.push_back(c->row_r); p.push_back(pk.delta1);
-    if ((e = make_set(c, &c->A, w, p, false))) return e;
+    if ((e = make_set(c, &c->A, w, p, false, cw[0]))) return e;
   }
   {
     std::vector<uint32_t> w = pk.B1_w;
     std::vector<G1Affine> p = pk.B1;
     merge_point(w, p, 0u, pk.beta1);
     w.push_back(c->row_s); p.push_back(pk.delta1);
-    if ((e = make_set(c, &c->B1, w, p, false))) return e;
+    if ((e = make_set(c, &c->B1, w, p, false, cw[1]))) return e;
   }
   {
     std::vector<uint32_t> w = pk.B2_w;
     std::vector<G2Affine> p = pk.B2;
     merge_point(w, p, 0u, pk.beta2);
     w.push_back(c->row_s); p.push_back(pk.delta2);
-    if ((e = make_set(c, &c->B2, w, p, false))) return e;
+    if ((e = make_set(c, &c->B2, w, p, false, cw[6]))) return e;
   }
   {
     std::vector<uint32_t> w = pk.K_w;
     std::vector<G1Affine> p = pk.K;
     w.push_back(c->row_rs); p.push_back(pk.delta1.neg());
-    if ((e = make_set(c, &c->K, w, p, false))) return e;
+    if ((e = make_set(c, &c->K, w, p, false, cw[2]))) return e;
   }
   {
     // h comes out of the last DIF pass in bit-reversed order: row `pos` holds h_{bitrev(pos)}
@@ -629,10 +656,10 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
       w.push_back(pos);
       p.push_back(pk.Z[i]);
     }
-    if ((e = make_set(c, &c->Z, w, p, true))) return e;
+    if ((e = make_set(c, &c->Z, w, p, true, cw[3]))) return e;
   }
-  if ((e = make_set(c, &c->CB, pk.CB_w, pk.CB, false))) return e;
-  if ((e = make_set(c, &c->CS, pk.CS_w, pk.CS, false))) return e;
+  if ((e = make_set(c, &c->CB, pk.CB_w, pk.CB, false, cw[4]))) return e;
+  if ((e = make_set(c, &c->CS, pk.CS_w, pk.CS, false, cw[5]))) return e;
   if ((e = build_pending(c))) return e;
 
   for (int k = 0; k < 2; k++) {
@@ -674,6 +701,11 @@ extern "C" int spp_circuit_info(const spp_circuit* c, uint32_t info[8]) {
   return SPP_OK;
 }
 extern "C" uint64_t spp_circuit_table_bytes(const spp_circuit* c) { return c ? c->table_bytes : 0; }
+extern "C" int spp_circuit_msm_windows(const spp_circuit* c, uint32_t bits[7]) {
+  if (!c || !bits) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  bits[0] = c->A.c; bits[1] = c->B1.c; bits[2] = c->K.c; bits[3] = c->Z.c; bits[4] = c->CB.c; bits[5] = c->CS.c; bits[6] = c->B2.c;
+  return SPP_OK;
+}
 extern "C" int spp_circuit_msm_sizes(const spp_circuit* c, uint32_t sizes[7]) {
   if (!c || !sizes) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
   sizes[0] = c->A.N; sizes[1] = c->B1.N; sizes[2] = c->K.N; sizes[3] = c->Z.N; sizes[4] = c->CB.N; sizes[5] = c->CS.N; sizes[6] = c->B2.N;
@@ -725,7 +757,7 @@ static void run_msm(spp_circuit* c, Workspace& w, const MsmSet<F>& s, MsmBuf<F>&
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
   if (timed && w.msm_ev_used < w.msm_ev.size()) ev = &w.msm_ev[w.msm_ev_used++];
   if (ev) hipEventRecord(ev->first, st);
-  launch_msm_accumulate<F>(st, s.table, s.rows, scal, b.partial, s.N, P, c->c_bits, S);
+  launch_msm_accumulate<F>(st, s.table, s.rows, scal, b.partial, s.N, P, s.c, S);
   if (ev) hipEventRecord(ev->second, st);
   launch_msm_reduce<F>(st, b.partial, b.out, P, s.N ? S : 0);
 }

@@ -87,6 +87,11 @@ class CircuitHandle:
         check(self.L.spp_circuit_msm_sizes(self.h, s))
         return list(s)
 
+    def msm_windows(self):
+        s = (ctypes.c_uint32 * 7)()
+        check(self.L.spp_circuit_msm_windows(self.h, s))
+        return list(s)
+
     @property
     def table_bytes(self):
         return int(self.L.spp_circuit_table_bytes(self.h))

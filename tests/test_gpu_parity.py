@@ -139,13 +139,13 @@ def test_unsatisfied_inputs_are_refused(withdraw_handle, withdraw_kat):
 
 
 def test_odd_batch_sizes_and_default_window(ctx, withdraw_artifacts, withdraw_kat):
-    """P = 1, 3, 70 (not multiples of the wavefront) and automatically sized window tables (budget 20 GB -> c = 9)."""
+    """P = 1, 3, 70 (not multiples of the wavefront) and automatically sized per-set window tables (20 GB budget)."""
     from oracle import native
     os.environ["SPP_TABLE_BUDGET_GB"] = "20"
     h = ctx.load_circuit(withdraw_artifacts["sppc"], withdraw_artifacts["pk"], 0)
     del os.environ["SPP_TABLE_BUDGET_GB"]
     try:
-        assert h.window_bits == 9 and h.table_bytes <= 20e9
+        assert h.table_bytes <= 20e9 and 8 <= min(h.msm_windows()[:4]) and len(set(h.msm_windows())) > 1
         orc = native.Prover(withdraw_artifacts["sppc"], withdraw_artifacts["pk"])
         rows = _withdraw_variants(withdraw_kat, 4)
         for count in (1, 3, 70):
