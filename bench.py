@@ -78,12 +78,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # rehearsal switches (one-GPU boxes): SPP_BENCH_BACKEND=gloo runs the collectives on CPU tensors and
+    # SPP_FORCE_DEVICE=k puts every rank on GPU k; the real multi-GPU run uses neither (nccl = RCCL, one GPU per rank)
+    backend = os.environ.get("SPP_BENCH_BACKEND", "nccl")
+    if "SPP_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["SPP_FORCE_DEVICE"])
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     dev = torch.device("cuda", local_rank)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     import spp
     from oracle import native
@@ -109,7 +118,7 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
             tb = time.time()
-            blob = broadcast_blob(dist, open(pkp, "rb").read() if rank == 0 else None, 0, dev)   # RCCL over xGMI
+            blob = broadcast_blob(dist, open(pkp, "rb").read() if rank == 0 else None, 0, coll_dev)   # RCCL over xGMI
             torch.cuda.synchronize()
             bcast_ms = (time.time() - tb) * 1e3
             if rank != 0:
@@ -162,7 +171,7 @@ def main():
             dist.barrier()
         elapsed = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         assert int(status[0].abs().sum().item()) + int(status[1].abs().sum().item()) == 0, "some synthetic proofs were refused"
