@@ -113,6 +113,11 @@ int spp_timings(spp_circuit* c, int which, float ms[9]);
 int spp_prove_withdraw(spp_circuit* c, const spp_withdraw_inputs* in, const uint8_t rs_seed[64], uint8_t proof[SPP_PROOF_LEN],
                        uint8_t pw[SPP_WITHDRAW_PW_LEN]);
 
+/* `sunspot verify <vk> <proof> <pw>` (noir_circuit/prove_linux.sh:86-87, audit_circuit/prove_audit.sh:98-99,
+ * scripts/generate_audit.py:687-691): host-side Groth16 + BSB22 check. *ok = 1 accepted, 0 rejected; the return value
+ * is an error only for malformed inputs. Needs no GPU. */
+int spp_verify(const uint8_t* vk, size_t vk_len, const uint8_t* proof, size_t proof_len, const uint8_t* pw, size_t pw_len, int* ok);
+
 /* debug / parity: full witness of proof 0 of the last batch, n_wires * 32 B big-endian */
 int spp_debug_witness(spp_circuit* c, uint8_t* out, size_t n_wires);
 

@@ -17,6 +17,7 @@
 #include "circuit.hpp"
 #include "kernels.hpp"
 #include "sha256.hpp"
+#include "pairing.hpp"
 
 using namespace spp;
 
@@ -1538,5 +1539,54 @@ extern "C" int spp_msm_g1_pippenger_bench(spp_ctx* ctx, size_t n, uint64_t seed,
   if (ms_total) *ms_total = tot / iters;
   if (ms_bucket_kernel) *ms_bucket_kernel = kern / iters;
   g1_to_raw(pippenger_finish(win), out);
+  return SPP_OK;
+}
+
+// -----------------------------------------------------------------------------------------------------
+// verification (host): `sunspot verify <vk> <proof> <pw>`
+// -----------------------------------------------------------------------------------------------------
+extern "C" int spp_verify(const uint8_t* vk, size_t vk_len, const uint8_t* proof, size_t proof_len, const uint8_t* pw, size_t pw_len,
+                          int* ok) {
+  if (!vk || !proof || !pw || !ok) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  *ok = 0;
+  if (proof_len != SPP_PROOF_LEN) return fail(SPP_ERR_FORMAT, "proof must be %d bytes", SPP_PROOF_LEN);
+  auto be32 = [](const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; };
+  if (vk_len < 576 + 4) return fail(SPP_ERR_FORMAT, "verifying key too short");
+  G1Affine alpha1 = g1_from_raw(vk);
+  G2Affine beta2 = g2_from_raw(vk + 128), gamma2 = g2_from_raw(vk + 256), delta2 = g2_from_raw(vk + 448);
+  uint32_t nk = be32(vk + 576);
+  size_t off = 580;
+  if (nk < 2 || vk_len != off + (size_t)nk * 64 + 12 + 256) return fail(SPP_ERR_FORMAT, "verifying key has the wrong length");
+  std::vector<G1Affine> K(nk);
+  for (uint32_t i = 0; i < nk; i++) K[i] = g1_from_raw(vk + off + 64 * (size_t)i);
+  off += (size_t)nk * 64;
+  if (be32(vk + off) != 1 || be32(vk + off + 4) != 0 || be32(vk + off + 8) != 1) return fail(SPP_ERR_FORMAT, "unsupported commitment layout");
+  G2Affine pedG = g2_from_raw(vk + off + 12), pedGS = g2_from_raw(vk + off + 12 + 128);
+  if (pw_len < 12) return fail(SPP_ERR_FORMAT, "public witness too short");
+  uint32_t npub = be32(pw);
+  if (be32(pw + 4) != 0 || be32(pw + 8) != npub || pw_len != 12 + 32 * (size_t)npub || npub + 2 != nk)
+    return fail(SPP_ERR_FORMAT, "public witness does not match the verifying key");
+  if (be32(proof + 256) != 1) return fail(SPP_ERR_FORMAT, "proof must carry exactly one commitment");
+  G1Affine Ar = g1_from_raw(proof), Krs = g1_from_raw(proof + 192), Cm = g1_from_raw(proof + 260), Pok = g1_from_raw(proof + 324);
+  G2Affine Bs = g2_from_raw(proof + 64);
+  if (!g1_on_curve(Ar) || !g1_on_curve(Krs) || !g1_on_curve(Cm) || !g1_on_curve(Pok) || !g2_on_curve(Bs)) return SPP_OK;   // ok = 0
+  // Pedersen proof of knowledge of the commitment
+  if (!pairing_product_is_one({{Cm, pedG}, {Pok, pedGS}})) return SPP_OK;
+  // challenge = hash_to_field(commitment, "bsb22-commitment")
+  const char* dst = "bsb22-commitment";
+  uint8_t u[48];
+  expand_message_xmd(proof + 260, 64, (const uint8_t*)dst, strlen(dst), u, 48);
+  uint32_t w12[12];
+  for (int k = 0; k < 12; k++) w12[k] = be32(u + 4 * k);
+  Fr challenge = fr_from_wide48(w12);
+  G1XYZZ ksum = G1XYZZ::from_affine(K[0]);
+  for (uint32_t i = 0; i <= npub; i++) {
+    Fr v = i < npub ? Fr::from_bytes_be(pw + 12 + 32 * (size_t)i) : challenge;
+    uint32_t lim[8];
+    v.to_canonical(lim);
+    ksum.add(scalar_mul(K[i + 1], lim));
+  }
+  ksum.madd(Cm);
+  if (pairing_product_is_one({{Ar, Bs}, {alpha1.neg(), beta2}, {ksum.to_affine().neg(), gamma2}, {Krs.neg(), delta2}})) *ok = 1;
   return SPP_OK;
 }

@@ -1,0 +1,100 @@
+"""`spp` command line: the four sunspot sub-commands the reference's scripts call, same positional arguments and
+output-file naming (outputs land next to the circuit file, as sunspot writes them next to the .ccs).
+
+    python -m spp.cli compile withdraw|audit [--rlwe-pk rlwe_pk.json] -o target/<name>.sppc     # prints nbConstraints=<n>
+    python -m spp.cli setup   target/<name>.sppc [--seed HEX32]                                   # -> <name>.pk, <name>.vk
+    python -m spp.cli prove   target/<name>.sppc target/<name>.pk Prover.toml                    # -> <name>.proof, <name>.pw
+    python -m spp.cli verify  target/<name>.vk target/<name>.proof target/<name>.pw              # exit 0 / 1
+
+Reference call sites: noir_circuit/prove_linux.sh:66-87, audit_circuit/prove_audit.sh:53-99,
+scripts/generate_audit.py:659-691, scripts/benchmark_all.py:646-690 (parses the `nbConstraints=` line).
+"""
+import argparse
+import json
+import os
+import re
+import sys
+
+from . import lib
+from .prover import Context, build_circuit, verify
+
+_AUDIT_KEYS = ("c0_packed", "c1_packed", "r", "e1_sparse", "e2", "k0", "k1")
+R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+def _num(tok):
+    tok = tok.strip().strip('"')
+    return int(tok, 16) if tok.lower().startswith("0x") else int(tok)
+
+
+def parse_prover_toml(text):
+    """Scalars and (possibly multi-line) arrays of quoted hex / bare integers, as written by
+    client/proof.helper.ts:32-50 and scripts/generate_audit.py:630-641."""
+    out = {}
+    for m in re.finditer(r'^(\w+)\s*=\s*(\[[^\]]*\]|[^\n]+)$', text, re.M):
+        k, v = m.group(1), m.group(2).strip()
+        if v.startswith("["):
+            out[k] = [_num(t) for t in re.findall(r'"[^"]*"|-?\w+', v[1:-1])]
+        else:
+            out[k] = _num(v)
+    return out
+
+
+def input_vector(vals):
+    """Circuit input wires (public first) from a parsed Prover.toml; the circuit is recognised by its keys."""
+    if "siblings" in vals:
+        order = ("root", "nullifier", "recipient", "amount", "wa_commitment", "secret_key", "owner_x", "owner_y", "randomness", "index")
+        return lib.SPP_CIRCUIT_WITHDRAW, [vals[k] % R for k in order] + [s % R for s in vals["siblings"]]
+    row = [vals["wa_commitment"], vals["ct_commitment"]] + vals["c0_packed"] + vals["c1_packed"] + [vals["secret_key"]]
+    for k in ("r", "e1_sparse", "e2", "k0", "k1"):
+        row += vals[k]
+    return lib.SPP_CIRCUIT_AUDIT, [v % R for v in row]
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="spp")
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    c = sub.add_parser("compile"); c.add_argument("circuit", choices=["withdraw", "audit"]); c.add_argument("--rlwe-pk"); c.add_argument("-o", "--out", required=True)
+    s = sub.add_parser("setup"); s.add_argument("sppc"); s.add_argument("--seed", default=None); s.add_argument("--device", type=int, default=0)
+    p = sub.add_parser("prove"); p.add_argument("sppc"); p.add_argument("pk"); p.add_argument("toml"); p.add_argument("--device", type=int, default=0)
+    p.add_argument("--window", type=int, default=0)
+    v = sub.add_parser("verify"); v.add_argument("vk"); v.add_argument("proof"); v.add_argument("pw")
+    a = ap.parse_args(argv)
+    if a.cmd == "compile":
+        aux = None
+        if a.circuit == "audit":
+            if not a.rlwe_pk:
+                ap.error("audit needs --rlwe-pk (demo-frontend/public/rlwe/rlwe_pk.json)")
+            pk = json.load(open(a.rlwe_pk))
+            aux = [_num(str(x)) for x in pk["a"]] + [_num(str(x)) for x in pk["b"]]
+        n = build_circuit(lib.SPP_CIRCUIT_WITHDRAW if a.circuit == "withdraw" else lib.SPP_CIRCUIT_AUDIT, a.out, aux)
+        print("nbConstraints=%d" % n)
+        return 0
+    if a.cmd == "setup":
+        base = os.path.splitext(a.sppc)[0]
+        seed = bytes.fromhex(a.seed) if a.seed else os.urandom(32)
+        ctx = Context(a.device)
+        ctx.setup(a.sppc, seed, base + ".pk", base + ".vk")
+        ctx.close()
+        return 0
+    if a.cmd == "prove":
+        base = os.path.splitext(a.sppc)[0]
+        _, row = input_vector(parse_prover_toml(open(a.toml).read()))
+        ctx = Context(a.device)
+        h = ctx.load_circuit(a.sppc, a.pk, a.window)
+        proofs, pws, status = h.prove_batch([row])
+        h.close()
+        ctx.close()
+        if status[0] != 0:
+            print("spp prove: inputs do not satisfy the circuit", file=sys.stderr)
+            return 1
+        open(base + ".proof", "wb").write(proofs[0])
+        open(base + ".pw", "wb").write(pws[0])
+        return 0
+    ok = verify(open(a.vk, "rb").read(), open(a.proof, "rb").read(), open(a.pw, "rb").read())
+    print("verification %s" % ("succeeded" if ok else "FAILED"))
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

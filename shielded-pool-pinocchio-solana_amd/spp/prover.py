@@ -14,6 +14,14 @@ def build_circuit(circuit_id, out_path, aux=None):
     return n.value
 
 
+def verify(vk_bytes, proof_bytes, pw_bytes):
+    """`sunspot verify vk proof pw`: True / False; raises SppError on malformed inputs. Host only (no GPU)."""
+    L = load_library()
+    ok = ctypes.c_int(0)
+    check(L.spp_verify(vk_bytes, len(vk_bytes), proof_bytes, len(proof_bytes), pw_bytes, len(pw_bytes), ctypes.byref(ok)))
+    return bool(ok.value)
+
+
 class Context:
     def __init__(self, device=0):
         self.L = load_library()

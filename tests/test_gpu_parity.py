@@ -334,3 +334,22 @@ def test_pippenger_matches_oracle_and_is_linear(ctx):
     basesb = b"".join(B.g1_to_bytes(B.g1_mul(B.G1_GEN, kk)) for kk in ks)
     native.lib().orc_msm_g1(basesb, b"".join(s.to_bytes(32, "big") for s in ss), 1 << 12, ctypes.cast(out, ctypes.c_void_p))
     assert r3 == out.raw
+
+
+def test_cli_setup_prove_verify_on_gpu(tmp_path, withdraw_kat):
+    """The prove_linux.sh pipeline (compile -> setup -> prove -> verify) through the spp CLI."""
+    from spp import cli
+    from spp.proof_helper import ShieldedPoolInputs, prover_toml
+    sppc = str(tmp_path / "shielded_pool_verifier.sppc")
+    assert cli.main(["compile", "withdraw", "-o", sppc]) == 0
+    assert cli.main(["setup", sppc, "--seed", "11" * 32]) == 0
+    fields = ("root", "nullifier", "recipient", "amount", "wa_commitment", "secret_key", "owner_x", "owner_y", "randomness", "index", "siblings")
+    toml = tmp_path / "Prover.toml"
+    toml.write_text(prover_toml(ShieldedPoolInputs(**{f: withdraw_kat[f] for f in fields})))
+    base = str(tmp_path / "shielded_pool_verifier")
+    assert cli.main(["prove", sppc, base + ".pk", str(toml), "--window", "6"]) == 0
+    assert os.path.getsize(base + ".proof") == 388 and os.path.getsize(base + ".pw") == 172
+    assert cli.main(["verify", base + ".vk", base + ".proof", base + ".pw"]) == 0
+    bad = tmp_path / "Bad.toml"
+    bad.write_text(toml.read_text().replace('recipient = "0x0000', 'recipient = "0x0001', 1).replace(withdraw_kat["root"], withdraw_kat["nullifier"], 1))
+    assert cli.main(["prove", sppc, base + ".pk", str(bad), "--window", "6"]) == 1

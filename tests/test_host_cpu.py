@@ -174,3 +174,61 @@ def test_shard_ranges():
             assert rs[0][0] == 0 and rs[-1][1] == total
             assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
             assert max(b - a for a, b in rs) - min(b - a for a, b in rs) <= 1
+
+
+def test_product_verifier_agrees_with_oracle(withdraw_artifacts, audit_artifacts, withdraw_kat, rlwe_pk):
+    """spp_verify (host pairing in the product, `sunspot verify` equivalent) vs the oracle's Python verifier."""
+    import random
+    import spp
+    from oracle import native, groth16, circuit as C, rlwe
+    cases = []
+    p = native.Prover(withdraw_artifacts["sppc"], withdraw_artifacts["pk"])
+    rc, proof, pw = p.prove(C.withdraw_inputs(withdraw_kat), 3, 4)
+    cases.append((open(withdraw_artifacts["vk"], "rb").read(), proof, pw))
+    pa = native.Prover(audit_artifacts["sppc"], audit_artifacts["pk"])
+    row = rlwe.audit_input_vector(rlwe.audit_inputs(rlwe_pk["a"], rlwe_pk["b"], 12345, random.Random(999)))
+    rc, proof, pw = pa.prove(row, 5, 6)
+    cases.append((open(audit_artifacts["vk"], "rb").read(), proof, pw))
+    for vk, proof, pw in cases:
+        assert spp.verify(vk, proof, pw) and groth16.verify(vk, proof, pw)
+        for pos in (0, 70, 200, 259, 300, 387):                      # Ar, Bs, Krs, count, commitment, PoK
+            bad = bytearray(proof); bad[pos] ^= 1
+            try:
+                got = spp.verify(vk, bytes(bad), pw)
+            except spp.SppError:
+                got = False
+            assert got is False
+        pw2 = bytearray(pw); pw2[-1] ^= 1
+        assert not spp.verify(vk, proof, bytes(pw2))
+    with pytest.raises(spp.SppError):
+        spp.verify(cases[0][0], cases[0][1][:100], cases[0][2])      # truncated proof
+    assert not spp.verify(cases[0][0], cases[1][1], cases[0][2])     # proof of the other circuit
+
+
+def test_cli_compile_verify_and_toml(tmp_path, withdraw_artifacts, withdraw_kat, capsys):
+    from spp import cli
+    from spp.proof_helper import ShieldedPoolInputs, prover_toml
+    from oracle import native, circuit as C
+    out = str(tmp_path / "w.sppc")
+    assert cli.main(["compile", "withdraw", "-o", out]) == 0
+    assert capsys.readouterr().out.strip() == "nbConstraints=%d" % withdraw_artifacts["n_constraints"]   # benchmark_all.py:646 parses this
+    assert open(out, "rb").read() == open(withdraw_artifacts["sppc"], "rb").read()
+    k = withdraw_kat
+    fields = ("root", "nullifier", "recipient", "amount", "wa_commitment", "secret_key", "owner_x", "owner_y", "randomness", "index", "siblings")
+    cid, row = cli.input_vector(cli.parse_prover_toml(prover_toml(ShieldedPoolInputs(**{f: k[f] for f in fields}))))
+    assert cid == 1 and row == C.withdraw_inputs(k)
+    # audit Prover.toml as scripts/generate_audit.py:630-641 writes it (single-line arrays, negative values mod p)
+    from oracle import rlwe
+    fmt = rlwe.format_field
+    toml = "secret_key = %s\nwa_commitment = %s\nct_commitment = %s\n" % (fmt(12345), fmt(7), fmt(9))
+    arrs = {"c0_packed": [3] * 10, "c1_packed": [4] * 147, "r": [-1] * 1024, "e1_sparse": [2] * 64, "e2": [0] * 1024, "k0": [-5] * 64, "k1": [6] * 1024}
+    for name, vals in arrs.items():
+        toml += "%s = [%s]\n" % (name, ", ".join(fmt(v) for v in vals))
+    cid, row = cli.input_vector(cli.parse_prover_toml(toml))
+    assert cid == 2 and len(row) == 3360 and row[0] == 7 and row[2 + 157] == 12345 and row[2 + 157 + 1] == rlwe.BN254_R - 1 and row[-1] == 6
+    p = native.Prover(withdraw_artifacts["sppc"], withdraw_artifacts["pk"])
+    rc, proof, pw = p.prove(C.withdraw_inputs(k), 1, 2)
+    (tmp_path / "a.proof").write_bytes(proof); (tmp_path / "a.pw").write_bytes(pw)
+    assert cli.main(["verify", withdraw_artifacts["vk"], str(tmp_path / "a.proof"), str(tmp_path / "a.pw")]) == 0
+    (tmp_path / "b.proof").write_bytes(bytes([proof[0] ^ 1]) + proof[1:])
+    assert cli.main(["verify", withdraw_artifacts["vk"], str(tmp_path / "b.proof"), str(tmp_path / "a.pw")]) == 1
