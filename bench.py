@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=0, help="proofs per GPU per step (0 = 1024 for withdraw, 256 for audit)")
+    ap.add_argument("--batch", type=int, default=0, help="proofs per GPU per step (0 = 2048 for withdraw, 512 for audit)")
     ap.add_argument("--circuit", default=os.environ.get("SPP_BENCH_CIRCUIT", "withdraw"), choices=["withdraw", "audit"])
     ap.add_argument("--window", type=int, default=int(os.environ.get("SPP_WINDOW", "0")), help="MSM window bits; 0 = auto (largest tables within the HBM budget)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -179,6 +179,12 @@ def main():
 
         out = None
         if rank == 0:
+            # the timed batches produced real proofs: check two of the last step with the product's own pairing verifier
+            last = (step_no[0] - 1) & 1
+            pbytes, wbytes = proofs[last].cpu().numpy().tobytes(), pws[last].cpu().numpy().tobytes()
+            vkb = open(vkp, "rb").read()
+            for i in (0, B - 1):
+                assert spp.verify(vkb, pbytes[388 * i:388 * (i + 1)], wbytes[h.pw_len * i:h.pw_len * (i + 1)]), "proof %d does not verify" % i
             total_proofs = B * world * steps
             value = total_proofs / elapsed
             sizes = h.msm_sizes()
@@ -230,7 +236,7 @@ def main():
         torch.cuda.empty_cache()
         return out
 
-    default_batch = {"withdraw": 1024, "audit": 256}
+    default_batch = {"withdraw": 2048, "audit": 512}
     main_res = run_circuit(args.circuit, args.batch or default_batch[args.circuit], args.steps, args.warmup, not args.no_cpu_baseline)
     # the other circuit of BASELINE.json's metric, as a secondary figure (single GPU runs only)
     other = None

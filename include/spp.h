@@ -149,6 +149,14 @@ int spp_grumpkin_keygen_batch(spp_ctx* ctx, size_t count, const uint8_t* sk, uin
 /* ct_commitment sponge (ct_helper/src/main.nr:15-34): in = count * n * 32 B, out = count * 32 B */
 int spp_poseidon2_sponge_batch(spp_ctx* ctx, size_t count, uint32_t n, const uint8_t* in, uint8_t* out);
 
+/* Everything scripts/generate_audit.py:468-641 computes before `nargo execute`, for `count` instances, on the GPU:
+ * keygen, wa_commitment, message slots, RLWE encryption + quotients, packing, ct_commitment -> rows of 3360 fields
+ * (32 B big-endian, main()'s parameter order :405-417) ready for spp_prove_batch on the audit circuit. */
+int spp_audit_inputs_batch(spp_ctx* ctx, const uint32_t* pk_a, const uint32_t* pk_b, size_t count, const uint8_t* sk, const int8_t* r,
+                           const int8_t* e1, const int8_t* e2, uint8_t* rows);
+int spp_audit_inputs_batch_device(spp_ctx* ctx, const void* d_pk_a, const void* d_pk_b, size_t count, const void* d_sk, const void* d_r,
+                                  const void* d_e1, const void* d_e2, void* d_rows);
+
 /* ---- micro-benchmark / unit entry points ---- */
 /* data: n = 2^logn elements, 32 B big-endian each, natural order in and out */
 int spp_ntt_fr(spp_ctx* ctx, uint8_t* data, uint32_t logn, int inverse);

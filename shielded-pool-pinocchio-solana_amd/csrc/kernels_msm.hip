@@ -143,14 +143,13 @@ struct Recoder {
 template <class F>
 __global__ void __launch_bounds__(256) k_msm_fixed(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ rows,
                                                    const Fr* __restrict__ scalars, XYZZ<F>* __restrict__ partial, uint32_t N,
-                                                   uint32_t P, uint32_t c, uint32_t Wn, uint32_t S, uint32_t L) {
+                                                   uint32_t P, uint32_t c, uint32_t Wn, uint32_t S) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= S * P) return;
   const uint32_t p = g % P, slice = g / P;
   const uint32_t E = 1u << (c - 1);
   // slice s takes bases s, s+S, s+2S, ...: neighbouring wires have similar scalar sizes (runs of bits, runs of hash
   // states), so a strided split gives every slice the same mix and the launch no tail of heavy slices
-  (void)L;
   XYZZ<F> acc = XYZZ<F>::infinity();
   for (uint32_t i = slice; i < N; i += S) {
     Fr s = scalars[(size_t)rows[i] * P + p];
@@ -198,10 +197,9 @@ template <class F>
 void launch_msm_accumulate(hipStream_t st, const Affine<F>* table, const uint32_t* rows, const Fr* scalars, XYZZ<F>* partial, uint32_t N,
                            uint32_t P, uint32_t c, uint32_t S) {
   if (N == 0 || S == 0) return;
-  uint32_t L = (N + S - 1) / S;
   uint64_t lanes = (uint64_t)S * P;
   hipLaunchKernelGGL(k_msm_fixed<F>, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, st, table, rows, scalars, partial, N, P, c,
-                     msm_windows(c), S, L);
+                     msm_windows(c), S);
 }
 template <class F>
 void launch_msm_reduce(hipStream_t st, const XYZZ<F>* partial, XYZZ<F>* out, uint32_t P, uint32_t S) {

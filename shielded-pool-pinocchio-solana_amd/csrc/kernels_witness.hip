@@ -310,4 +310,68 @@ void launch_poseidon2_sponge(hipStream_t st, HashConsts hc, const uint8_t* in_be
   if (count) hipLaunchKernelGGL(k_poseidon2_sponge, dim3((count + 63) / 64), dim3(64), 0, st, hc, in_be, n, out_be, count);
 }
 
+
+// ----------------------------------------------------------------------------------------------------
+// audit input assembly: (sk, r, e1, e2) -> the 3360-field input row of the audit circuit, all on the device
+// (scripts/generate_audit.py:468-641: keygen, message slots, encryption + quotients, packing, commitments, Prover.toml)
+// ----------------------------------------------------------------------------------------------------
+// message = little-endian bytes of owner_x then owner_y (generate_audit.py:489-496); xy_be is 64 B big-endian per key
+__global__ void __launch_bounds__(256) k_audit_msg(const uint8_t* __restrict__ xy_be, uint8_t* __restrict__ msg, uint32_t count) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= count * 64) return;
+  const uint32_t inst = g / 64, s = g % 64;
+  msg[g] = xy_be[(size_t)inst * 64 + (s < 32 ? 31 - s : 32 + 31 - (s - 32))];
+}
+__device__ __forceinline__ void store_small_signed_be(uint8_t* o, int32_t v) {
+  // field encoding of a small signed integer (format_field, generate_audit.py:77-82): v >= 0 -> v, v < 0 -> r - |v|
+  const uint8_t RBE[32] = {0x30, 0x64, 0x4e, 0x72, 0xe1, 0x31, 0xa0, 0x29, 0xb8, 0x50, 0x45, 0xb6, 0x81, 0x81, 0x58, 0x5d,
+                           0x28, 0x33, 0xe8, 0x48, 0x79, 0xb9, 0x70, 0x91, 0x43, 0xe1, 0xf5, 0x93, 0xf0, 0x00, 0x00, 0x01};
+  uint32_t low;
+  if (v >= 0) {
+    for (int i = 0; i < 28; i++) o[i] = 0;
+    low = (uint32_t)v;
+  } else {
+    for (int i = 0; i < 28; i++) o[i] = RBE[i];
+    low = 0xf0000001u - (uint32_t)(-(int64_t)v);   // |v| <= 2^31 < 0xf0000001: no borrow into the upper limbs
+  }
+  o[28] = (uint8_t)(low >> 24); o[29] = (uint8_t)(low >> 16); o[30] = (uint8_t)(low >> 8); o[31] = (uint8_t)low;
+}
+static constexpr uint32_t AUDIT_NIN = 3360;
+__global__ void __launch_bounds__(256) k_audit_assemble(const uint8_t* __restrict__ wa_be, const uint8_t* __restrict__ ct_be,
+                                                        const uint8_t* __restrict__ packed_be, const uint8_t* __restrict__ sk_be,
+                                                        const int8_t* __restrict__ r, const int8_t* __restrict__ e1, const int8_t* __restrict__ e2,
+                                                        const int32_t* __restrict__ k0, const int32_t* __restrict__ k1,
+                                                        uint8_t* __restrict__ rows, uint32_t count) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (uint64_t)count * AUDIT_NIN) return;
+  const uint32_t inst = (uint32_t)(g / AUDIT_NIN), f = (uint32_t)(g % AUDIT_NIN);
+  uint8_t* o = rows + g * 32;
+  const uint8_t* src = nullptr;
+  if (f == 0) src = wa_be + (size_t)inst * 32;
+  else if (f == 1) src = ct_be + (size_t)inst * 32;
+  else if (f < 2 + 157) src = packed_be + ((size_t)inst * 157 + (f - 2)) * 32;
+  else if (f == 159) src = sk_be + (size_t)inst * 32;
+  if (src) {
+    for (int i = 0; i < 32; i++) o[i] = src[i];
+    return;
+  }
+  uint32_t k = f - 160;
+  int32_t v;
+  if (k < 1024) v = r[(size_t)inst * 1024 + k];
+  else if ((k -= 1024) < 64) v = e1[(size_t)inst * 64 + k];
+  else if ((k -= 64) < 1024) v = e2[(size_t)inst * 1024 + k];
+  else if ((k -= 1024) < 64) v = k0[(size_t)inst * 64 + k];
+  else v = k1[(size_t)inst * 1024 + (k - 64)];
+  store_small_signed_be(o, v);
+}
+void launch_audit_msg(hipStream_t st, const uint8_t* xy_be, uint8_t* msg, uint32_t count) {
+  if (count) hipLaunchKernelGGL(k_audit_msg, dim3((count * 64 + 255) / 256), dim3(256), 0, st, xy_be, msg, count);
+}
+void launch_audit_assemble(hipStream_t st, const uint8_t* wa_be, const uint8_t* ct_be, const uint8_t* packed_be, const uint8_t* sk_be,
+                           const int8_t* r, const int8_t* e1, const int8_t* e2, const int32_t* k0, const int32_t* k1, uint8_t* rows,
+                           uint32_t count) {
+  uint64_t lanes = (uint64_t)count * AUDIT_NIN;
+  if (count) hipLaunchKernelGGL(k_audit_assemble, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, st, wa_be, ct_be, packed_be, sk_be, r, e1, e2, k0, k1, rows, count);
+}
+
 }  // namespace spp

@@ -171,6 +171,12 @@ struct Workspace {
   size_t msm_ev_used = 0;
 };
 
+template <class F>
+struct PendingTable {
+  std::vector<Affine<F>> pts;
+  Affine<F>* table;
+  uint32_t c;
+};
 struct SolveStep {
   enum Kind { SEQ, BATCH_DIV, COUNT8, COMMIT } kind;
   uint32_t a = 0, b = 0, c = 0;   // SEQ: [pc_begin, pc_end) ; BATCH_DIV: k0, n ; COUNT8: h0, n, out0
@@ -192,7 +198,11 @@ struct spp_circuit {
   std::vector<void*> owned;
   Workspace ws[2];
   int next_ws = 0, last_ws = 0;
+  std::vector<PendingTable<Fq>> pending1;    // tables allocated but not yet built (spp_load_circuit)
+  std::vector<PendingTable<Fq2>> pending2;
 };
+static std::vector<PendingTable<Fq>>& pending(spp_circuit* c, Fq*) { return c->pending1; }
+static std::vector<PendingTable<Fq2>>& pending(spp_circuit* c, Fq2*) { return c->pending2; }
 
 template <class T>
 static int own_upload(spp_circuit* c, T** dst, const std::vector<T>& src) {
@@ -275,16 +285,6 @@ static int build_table_chunked(spp_circuit* c, const std::vector<Affine<F>>& pts
   return build_table<F>(c, pts, cbits, *table_out, std::min(table_temp_budget(), (size_t)2 << 30));
 }
 
-template <class F>
-struct PendingTable {
-  std::vector<Affine<F>> pts;
-  Affine<F>* table;
-  uint32_t c;
-};
-static std::vector<PendingTable<Fq>> g_pending1;    // guarded by ctx->mu (spp_load_circuit holds it)
-static std::vector<PendingTable<Fq2>> g_pending2;
-static std::vector<PendingTable<Fq>>& pending(Fq*) { return g_pending1; }
-static std::vector<PendingTable<Fq2>>& pending(Fq2*) { return g_pending2; }
 
 template <class F>
 static int make_set(spp_circuit* c, MsmSet<F>* set, const std::vector<uint32_t>& rows, const std::vector<Affine<F>>& pts, bool from_h,
@@ -294,16 +294,16 @@ static int make_set(spp_circuit* c, MsmSet<F>* set, const std::vector<uint32_t>&
   set->c = cbits;
   if (int e = own_upload(c, &set->rows, rows)) return e;
   if (int e = alloc_table<F>(c, pts.size(), cbits, &set->table)) return e;
-  pending((F*)nullptr).push_back({pts, set->table, cbits});
+  pending(c, (F*)nullptr).push_back({pts, set->table, cbits});
   return 0;
 }
 static int build_pending(spp_circuit* c) {
   const size_t budget = table_temp_budget();
   int e = 0;
-  for (auto& p : g_pending1) if (!e) e = build_table<Fq>(c, p.pts, p.c, p.table, budget);
-  for (auto& p : g_pending2) if (!e) e = build_table<Fq2>(c, p.pts, p.c, p.table, budget);
-  g_pending1.clear();
-  g_pending2.clear();
+  for (auto& p : pending(c, (Fq*)nullptr)) if (!e) e = build_table<Fq>(c, p.pts, p.c, p.table, budget);
+  for (auto& p : pending(c, (Fq2*)nullptr)) if (!e) e = build_table<Fq2>(c, p.pts, p.c, p.table, budget);
+  pending(c, (Fq*)nullptr).clear();
+  pending(c, (Fq2*)nullptr).clear();
   return e;
 }
 
@@ -829,7 +829,9 @@ extern "C" int spp_prove_batch_device(spp_circuit* c, size_t count, const void* 
   Workspace& w = c->ws[c->next_ws];
   c->last_ws = c->next_ws;
   c->next_ws ^= 1;
-  if (int e = ensure_workspace(c, w, count)) return e;
+  // size BOTH workspaces on the first call, so that no allocation ever lands inside a caller's timed / pipelined region
+  if (int e = ensure_workspace(c, c->ws[0], count)) return e;
+  if (int e = ensure_workspace(c, c->ws[1], count)) return e;
   return prove_on_device(c, w, (uint32_t)count, (const uint8_t*)d_inputs, (const uint8_t*)d_rs, (uint8_t*)d_proofs, (uint8_t*)d_pws,
                          (uint32_t*)d_status);
 }
@@ -1588,5 +1590,59 @@ extern "C" int spp_verify(const uint8_t* vk, size_t vk_len, const uint8_t* proof
   }
   ksum.madd(Cm);
   if (pairing_product_is_one({{Ar, Bs}, {alpha1.neg(), beta2}, {ksum.to_affine().neg(), gamma2}, {Krs.neg(), delta2}})) *ok = 1;
+  return SPP_OK;
+}
+
+// -----------------------------------------------------------------------------------------------------
+// audit inputs end to end on the device: (sk, r, e1, e2) -> 3360-field rows for spp_prove_batch(_device)
+// -----------------------------------------------------------------------------------------------------
+static int audit_inputs_on_device(spp_ctx* ctx, const uint32_t* d_pk_a, const uint32_t* d_pk_b, uint32_t count, const uint8_t* d_sk,
+                                  const int8_t* d_r, const int8_t* d_e1, const int8_t* d_e2, uint8_t* d_rows) {
+  hipStream_t st = ctx->stream;
+  DevBuf xy, msg, c0, c1, k0, k1, packed, ct, wa;
+  HIP_TRY(xy.alloc((size_t)count * 64)); HIP_TRY(msg.alloc((size_t)count * 64));
+  HIP_TRY(c0.alloc((size_t)count * 64 * 4)); HIP_TRY(c1.alloc((size_t)count * 1024 * 4));
+  HIP_TRY(k0.alloc((size_t)count * 64 * 4)); HIP_TRY(k1.alloc((size_t)count * 1024 * 4));
+  HIP_TRY(packed.alloc((size_t)count * 157 * 32)); HIP_TRY(ct.alloc((size_t)count * 32)); HIP_TRY(wa.alloc((size_t)count * 32));
+  launch_grumpkin_keygen(st, ctx->gk_table, d_sk, xy.as<uint8_t>(), count);                       // generate_audit.py:482
+  launch_poseidon_hash(st, ctx->hc, xy.as<uint8_t>(), 2, wa.as<uint8_t>(), count);                 // wa_commitment
+  launch_audit_msg(st, xy.as<uint8_t>(), msg.as<uint8_t>(), count);                                // :489-496
+  launch_rlwe_witness(st, d_pk_a, d_pk_b, d_r, d_e1, d_e2, msg.as<uint8_t>(), c0.as<uint32_t>(), c1.as<uint32_t>(), k0.as<int32_t>(),
+                      k1.as<int32_t>(), packed.as<uint8_t>(), count);                              // :507-584
+  launch_poseidon2_sponge(st, ctx->hc, packed.as<uint8_t>(), 157, ct.as<uint8_t>(), count);        // ct_commitment :587
+  launch_audit_assemble(st, wa.as<uint8_t>(), ct.as<uint8_t>(), packed.as<uint8_t>(), d_sk, d_r, d_e1, d_e2, k0.as<int32_t>(),
+                        k1.as<int32_t>(), d_rows, count);                                          // Prover.toml order :630-641
+  HIP_TRY(hipStreamSynchronize(st));   // temporaries are released on return
+  HIP_TRY(hipGetLastError());
+  return SPP_OK;
+}
+extern "C" int spp_audit_inputs_batch_device(spp_ctx* ctx, const void* d_pk_a, const void* d_pk_b, size_t count, const void* d_sk,
+                                             const void* d_r, const void* d_e1, const void* d_e2, void* d_rows) {
+  if (!ctx || !d_pk_a || !d_pk_b || !d_sk || !d_r || !d_e1 || !d_e2 || !d_rows) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  if (count == 0) return SPP_OK;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (int e = ensure_ctx_consts(ctx)) return e;
+  return audit_inputs_on_device(ctx, (const uint32_t*)d_pk_a, (const uint32_t*)d_pk_b, (uint32_t)count, (const uint8_t*)d_sk,
+                                (const int8_t*)d_r, (const int8_t*)d_e1, (const int8_t*)d_e2, (uint8_t*)d_rows);
+}
+extern "C" int spp_audit_inputs_batch(spp_ctx* ctx, const uint32_t* pk_a, const uint32_t* pk_b, size_t count, const uint8_t* sk,
+                                      const int8_t* r, const int8_t* e1, const int8_t* e2, uint8_t* rows) {
+  if (!ctx || !pk_a || !pk_b || !sk || !r || !e1 || !e2 || !rows) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  if (count == 0) return SPP_OK;
+  for (int i = 0; i < 1024; i++)
+    if (pk_a[i] >= 167772161u || pk_b[i] >= 167772161u) return fail(SPP_ERR_BAD_INPUT, "public key coefficient not in [0, q)");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (int e = ensure_ctx_consts(ctx)) return e;
+  hipStream_t st = ctx->stream;
+  DevBuf da, db, ds, dr, de1, de2, drows;
+  UP(da, pk_a, 4096); UP(db, pk_b, 4096); UP(ds, sk, count * 32);
+  UP(dr, r, count * 1024); UP(de1, e1, count * 64); UP(de2, e2, count * 1024);
+  HIP_TRY(drows.alloc(count * 3360 * 32));
+  if (int e = audit_inputs_on_device(ctx, da.as<uint32_t>(), db.as<uint32_t>(), (uint32_t)count, ds.as<uint8_t>(), dr.as<int8_t>(),
+                                     de1.as<int8_t>(), de2.as<int8_t>(), drows.as<uint8_t>()))
+    return e;
+  HIP_TRY(hipMemcpy(rows, drows.p, count * 3360 * 32, hipMemcpyDeviceToHost));
   return SPP_OK;
 }

@@ -67,6 +67,8 @@ def load_library():
     L.spp_merkle_build.argtypes = [vp, sz, u32, cp, sz, vp, vp, vp]
     L.spp_grumpkin_keygen_batch.argtypes = [vp, sz, cp, vp]
     L.spp_poseidon2_sponge_batch.argtypes = [vp, sz, u32, cp, vp]
+    L.spp_audit_inputs_batch.argtypes = [vp, vp, vp, sz, cp, vp, vp, vp, vp]
+    L.spp_audit_inputs_batch_device.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp, vp]
     L.spp_ntt_fr.argtypes = [vp, vp, u32, i32]
     L.spp_msm_g1.argtypes = [vp, cp, cp, sz, i32, vp]
     L.spp_msm_g1_pippenger.argtypes = [vp, cp, cp, sz, vp]

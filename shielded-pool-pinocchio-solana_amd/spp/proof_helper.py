@@ -114,3 +114,54 @@ def generateProof(config: CircuitConfig, inputs: ShieldedPoolInputs, rs=None):
 
 
 generate_proof = generateProof
+
+BN254_R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+_AUDIT_ORDER = ("secret_key", "wa_commitment", "ct_commitment", "c0_packed", "c1_packed", "r", "e1_sparse", "e2", "k0", "k1")
+
+
+def _format_field(v):
+    """scripts/generate_audit.py:77-82."""
+    v = _field(v) % BN254_R
+    return '"0"' if v == 0 else '"0x%064x"' % v
+
+
+def audit_prover_toml(inputs: dict) -> str:
+    """Text of scripts/generate_audit.py:630-641 (same key order, single-line arrays)."""
+    out = ""
+    for k in _AUDIT_ORDER:
+        v = inputs[k]
+        if isinstance(v, (list, tuple)):
+            out += "%s = [%s]\n" % (k, ", ".join(_format_field(x) for x in v))
+        else:
+            out += "%s = %s\n" % (k, _format_field(v))
+    return out
+
+
+def generateAuditProof(config: CircuitConfig, inputs: dict, rs=None):
+    """Audit-circuit counterpart of generateProof (the reference proves it from a shell script,
+    audit_circuit/prove_audit.sh:74-99 / scripts/generate_audit.py:668-685): inputs carry the Prover.toml keys
+    secret_key, wa_commitment, ct_commitment, c0_packed[10], c1_packed[147], r[1024], e1_sparse[64], e2[1024],
+    k0[64], k1[1024] (signed values allowed). Returns {"proof": 388 B, "publicWitness": 76 B}."""
+    from .lib import SPP_CIRCUIT_AUDIT
+    with open(os.path.join(config.circuitDir, "Prover.toml"), "w") as f:
+        f.write(audit_prover_toml(inputs))
+    h = _handle(config)
+    if h.circuit_id != SPP_CIRCUIT_AUDIT:
+        raise ValueError("generateAuditProof expects the audit circuit")
+    row = [_field(inputs["wa_commitment"]), _field(inputs["ct_commitment"])] + [_field(v) for v in inputs["c0_packed"]] + \
+          [_field(v) for v in inputs["c1_packed"]] + [_field(inputs["secret_key"])]
+    for k in ("r", "e1_sparse", "e2", "k0", "k1"):
+        row += [_field(v) for v in inputs[k]]
+    row = [v % BN254_R for v in row]
+    proofs, pws, status = h.prove_batch([row], None if rs is None else [rs])
+    if status[0] != 0:
+        raise SppError(status[0], "inputs do not satisfy the circuit (Command failed: sunspot prove)")
+    target = os.path.join(config.circuitDir, "target")
+    with open(os.path.join(target, config.circuitName + ".proof"), "wb") as f:
+        f.write(proofs[0])
+    with open(os.path.join(target, config.circuitName + ".pw"), "wb") as f:
+        f.write(pws[0])
+    return {"proof": proofs[0], "publicWitness": pws[0]}
+
+
+generate_audit_proof = generateAuditProof

@@ -110,3 +110,18 @@ def ct_commitments(ctx, packed_rows):
     out = ctypes.create_string_buffer(32 * count)
     check(ctx.L.spp_poseidon2_sponge_batch(ctx.h, count, n, _be(v for r in packed_rows for v in r), ctypes.cast(out, ctypes.c_void_p)))
     return _unbe(out.raw, count)
+
+
+def audit_input_rows(ctx, pk_a, pk_b, secret_keys, r, e1, e2):
+    """scripts/generate_audit.py:468-641 for a batch, on the GPU: returns one 3360-element input row per instance
+    (wa_commitment, ct_commitment, c0_packed, c1_packed, secret_key, r, e1_sparse, e2, k0, k1 as field elements)."""
+    count = len(secret_keys)
+    r = np.ascontiguousarray(r, dtype=np.int8).reshape(count, RLWE_N)
+    e1 = np.ascontiguousarray(e1, dtype=np.int8).reshape(count, MSG_SLOTS)
+    e2 = np.ascontiguousarray(e2, dtype=np.int8).reshape(count, RLWE_N)
+    a = np.ascontiguousarray(pk_a, dtype=np.uint32)
+    b = np.ascontiguousarray(pk_b, dtype=np.uint32)
+    rows = np.zeros((count, 3360 * 32), dtype=np.uint8)
+    p = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+    check(ctx.L.spp_audit_inputs_batch(ctx.h, p(a), p(b), count, _be(secret_keys), p(r), p(e1), p(e2), p(rows)))
+    return [_unbe(rows[i].tobytes(), 3360) for i in range(count)]

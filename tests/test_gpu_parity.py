@@ -353,3 +353,52 @@ def test_cli_setup_prove_verify_on_gpu(tmp_path, withdraw_kat):
     bad = tmp_path / "Bad.toml"
     bad.write_text(toml.read_text().replace('recipient = "0x0000', 'recipient = "0x0001', 1).replace(withdraw_kat["root"], withdraw_kat["nullifier"], 1))
     assert cli.main(["prove", sppc, base + ".pk", str(bad), "--window", "6"]) == 1
+
+
+def test_audit_inputs_pipeline_on_gpu(ctx, rlwe_pk):
+    """(sk, r, e1, e2) -> full audit input rows on the device == the oracle's restatement of generate_audit.py:468-641."""
+    from spp import witness
+    from oracle import rlwe
+    sks, rs, e1s, e2s, exp = [], [], [], [], []
+    for i in range(5):
+        d = rlwe.audit_inputs(rlwe_pk["a"], rlwe_pk["b"], 12345 + 7 * i, random.Random(999 + i))   # i = 0: the reference's own run
+        sks.append(d["secret_key"]); rs.append(d["r"]); e1s.append(d["e1"]); e2s.append(d["e2"])
+        exp.append(rlwe.audit_input_vector(d))
+    got = witness.audit_input_rows(ctx, rlwe_pk["a"], rlwe_pk["b"], sks, rs, e1s, e2s)
+    assert got == exp
+
+
+def test_host_mirror_generate_proof_and_audit_proof(tmp_path, withdraw_artifacts, audit_artifacts, withdraw_kat, rlwe_pk):
+    """spp.generateProof / generateAuditProof: same call shape and side effects as client/proof.helper.ts:28-72."""
+    import shutil
+    import spp
+    from spp import proof_helper
+    from oracle import rlwe
+    os.environ["SPP_TABLE_BUDGET_GB"] = "12"
+    try:
+        wdir = tmp_path / "noir_circuit"; os.makedirs(wdir / "target")
+        shutil.copy(withdraw_artifacts["sppc"], wdir / "target" / "shielded_pool_verifier.sppc")
+        shutil.copy(withdraw_artifacts["pk"], wdir / "target" / "shielded_pool_verifier.pk")
+        fields = ("root", "nullifier", "recipient", "amount", "wa_commitment", "secret_key", "owner_x", "owner_y", "randomness", "index", "siblings")
+        inputs = spp.ShieldedPoolInputs(**{f: withdraw_kat[f] for f in fields})
+        out = spp.generateProof(spp.CircuitConfig(str(wdir), "shielded_pool_verifier"), inputs)
+        assert set(out) == {"proof", "publicWitness"} and len(out["proof"]) == 388 and len(out["publicWitness"]) == 172
+        assert (wdir / "Prover.toml").read_text() == proof_helper.prover_toml(inputs)
+        assert (wdir / "target" / "shielded_pool_verifier.proof").read_bytes() == out["proof"]
+        assert spp.verify(open(withdraw_artifacts["vk"], "rb").read(), out["proof"], out["publicWitness"])
+        bad = spp.ShieldedPoolInputs(**{**inputs.__dict__, "recipient": "0x0"})
+        with pytest.raises(spp.SppError):
+            spp.generateProof(spp.CircuitConfig(str(wdir), "shielded_pool_verifier"), bad)
+        adir = tmp_path / "audit_circuit"; os.makedirs(adir / "target")
+        shutil.copy(audit_artifacts["sppc"], adir / "target" / "rlwe_audit.sppc")
+        shutil.copy(audit_artifacts["pk"], adir / "target" / "rlwe_audit.pk")
+        d = rlwe.audit_inputs(rlwe_pk["a"], rlwe_pk["b"], 12345, random.Random(999))
+        ain = dict(secret_key=d["secret_key"], wa_commitment=d["wa_commitment"], ct_commitment=d["ct_commitment"], c0_packed=d["c0_packed"],
+                   c1_packed=d["c1_packed"], r=d["r"], e1_sparse=d["e1"], e2=d["e2"], k0=d["k0"], k1=d["k1"])
+        out = spp.generateAuditProof(spp.CircuitConfig(str(adir), "rlwe_audit"), ain)
+        assert len(out["proof"]) == 388 and len(out["publicWitness"]) == 76
+        assert spp.verify(open(audit_artifacts["vk"], "rb").read(), out["proof"], out["publicWitness"])
+        toml = (adir / "Prover.toml").read_text()
+        assert toml.startswith('secret_key = "0x%064x"\nwa_commitment = ' % 12345) and "\nk1 = [" in toml      # generate_audit.py:630-641
+    finally:
+        del os.environ["SPP_TABLE_BUDGET_GB"]
