@@ -52,7 +52,10 @@ SPP_HD uint32_t subb32(uint32_t a, uint32_t b, uint32_t& borrow) {
 }
 
 // --------------------------------------------------------------------------------------------------
-// Fp<Params>: element of GF(p) in Montgomery form (value * 2^256 mod p), always fully reduced (< p).
+// Fp<Params>: element of GF(p) in Montgomery form (value * 2^256 mod p), kept in the redundant range [0, 2p)
+// ("almost Montgomery"): with p < 2^254 a product of two such values reduces to < 1.76 p without the final
+// conditional subtraction, so mul/sqr never compare against p; add/sub fold back below 2p; only equality tests and
+// canonical output (to_canonical) finish the reduction.
 // --------------------------------------------------------------------------------------------------
 template <class Pm>
 struct Fp {
@@ -78,14 +81,23 @@ struct Fp {
     SPP_UNROLL for (int i = 0; i < 8; i++) r.l[i] = Pm::R3(i);
     return r;
   }
-  SPP_HD bool is_zero() const {
-    uint32_t o = 0;
-    SPP_UNROLL for (int i = 0; i < 8; i++) o |= l[i];
-    return o == 0;
+  SPP_HD bool is_zero() const {   // value is 0 or p
+    uint32_t o = 0, q = 0;
+    SPP_UNROLL for (int i = 0; i < 8; i++) {
+      o |= l[i];
+      q |= l[i] ^ Pm::MOD(i);
+    }
+    return o == 0 || q == 0;
+  }
+  SPP_HD Fp canonical() const {   // same element, limbs < p
+    Fp r = *this;
+    cond_sub(r.l);
+    return r;
   }
   SPP_HD bool operator==(const Fp& b) const {
+    const Fp x = canonical(), y = b.canonical();
     uint32_t o = 0;
-    SPP_UNROLL for (int i = 0; i < 8; i++) o |= l[i] ^ b.l[i];
+    SPP_UNROLL for (int i = 0; i < 8; i++) o |= x.l[i] ^ y.l[i];
     return o == 0;
   }
   SPP_HD bool operator!=(const Fp& b) const { return !(*this == b); }
@@ -105,29 +117,37 @@ struct Fp {
     SPP_UNROLL for (int i = 0; i < 8; i++) a[i] = br ? a[i] : t[i];
   }
 
+  // a -= 2p if a >= 2p (a < 4p < 2^256)
+  static SPP_HD void cond_sub_2p(uint32_t* a) {
+    uint32_t t[8];
+    uint32_t br = 0;
+    SPP_UNROLL for (int i = 0; i < 8; i++) t[i] = subb32(a[i], Pm::TWOP(i), br);
+    SPP_UNROLL for (int i = 0; i < 8; i++) a[i] = br ? a[i] : t[i];
+  }
+
   friend SPP_HD Fp operator+(const Fp& a, const Fp& b) {
     Fp r;
     uint32_t c = 0;
     SPP_UNROLL for (int i = 0; i < 8; i++) r.l[i] = addc32(a.l[i], b.l[i], c);
-    // p < 2^254 so a+b < 2^255: no carry out of limb 7
-    cond_sub(r.l);
+    // a, b < 2p < 2^255 so a+b < 2^256: no carry out of limb 7
+    cond_sub_2p(r.l);
     return r;
   }
   friend SPP_HD Fp operator-(const Fp& a, const Fp& b) {
     Fp r;
     uint32_t br = 0;
     SPP_UNROLL for (int i = 0; i < 8; i++) r.l[i] = subb32(a.l[i], b.l[i], br);
-    // add p back when the difference went negative (mask form: no divergent branch)
+    // add 2p back when the difference went negative (mask form: no divergent branch): result in [0, 2p)
     const uint32_t mask = 0u - br;
     uint32_t c = 0;
-    SPP_UNROLL for (int i = 0; i < 8; i++) r.l[i] = addc32(r.l[i], Pm::MOD(i) & mask, c);
+    SPP_UNROLL for (int i = 0; i < 8; i++) r.l[i] = addc32(r.l[i], Pm::TWOP(i) & mask, c);
     return r;
   }
   SPP_HD Fp neg() const {
-    if (is_zero()) return *this;
-    Fp r;
+    if (is_zero()) return zero();
+    Fp r;                                  // 2p - a in (0, 2p)
     uint32_t br = 0;
-    SPP_UNROLL for (int i = 0; i < 8; i++) r.l[i] = subb32(Pm::MOD(i), l[i], br);
+    SPP_UNROLL for (int i = 0; i < 8; i++) r.l[i] = subb32(Pm::TWOP(i), l[i], br);
     return r;
   }
   SPP_HD Fp dbl() const { return *this + *this; }
@@ -201,8 +221,7 @@ struct Fp {
     r.l[5] = (n[5] >> 10) | (n[6] << 19);
     r.l[6] = (n[6] >> 13) | (n[7] << 16);
     r.l[7] = (n[7] >> 16) | (n[8] << 13);
-    cond_sub(r.l);
-    return r;
+    return r;   // < 1.76 p for inputs < 2p (sum-of-two-products callers: see Fq2): no conditional subtraction
   }
   friend SPP_HD Fp operator*(const Fp& a, const Fp& b) {
     uint32_t a9[9], b9[9];
@@ -244,7 +263,8 @@ struct Fp {
   SPP_HD void to_canonical(uint32_t out[8]) const {
     Fp o;
     SPP_UNROLL for (int i = 0; i < 8; i++) o.l[i] = (i == 0);
-    Fp c = *this * o;  // a*R * 1 / R = a
+    Fp c = *this * o;  // a*R * 1 / R = a, <= p
+    cond_sub(c.l);
     SPP_UNROLL for (int i = 0; i < 8; i++) out[i] = c.l[i];
   }
   // from canonical limbs (must be < p)
@@ -366,7 +386,8 @@ struct Fq2 {
       }
     }
     Fq2 r;
-    r.c0 = Fq::reduce_columns(c);
+    r.c0 = Fq::reduce_columns(c);   // sum of two products of values < 2p: < 2.51 p
+    Fq::cond_sub_2p(r.c0.l);
     SPP_UNROLL for (int k = 0; k < 18; k++) c[k] = 0;
     SPP_UNROLL for (int i = 0; i < 9; i++) {
       SPP_UNROLL for (int j = 0; j < 9; j++) {
@@ -375,6 +396,7 @@ struct Fq2 {
       }
     }
     r.c1 = Fq::reduce_columns(c);
+    Fq::cond_sub_2p(r.c1.l);
     return r;
   }
   //   c0 = a0^2 + a1*(-a1),  c1 = (2 a0) * a1
@@ -393,12 +415,14 @@ struct Fq2 {
       SPP_UNROLL for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)a1[i] * n1[j];
     }
     Fq2 r;
-    r.c0 = Fq::reduce_columns(c);
+    r.c0 = Fq::reduce_columns(c);   // sum of two products of values < 2p: < 2.51 p
+    Fq::cond_sub_2p(r.c0.l);
     SPP_UNROLL for (int k = 0; k < 18; k++) c[k] = 0;
     SPP_UNROLL for (int i = 0; i < 9; i++) {
       SPP_UNROLL for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)d0[i] * a1[j];
     }
     r.c1 = Fq::reduce_columns(c);
+    Fq::cond_sub_2p(r.c1.l);
     return r;
   }
   SPP_HD Fq2 inv() const {
