@@ -11,7 +11,7 @@
 
 namespace spp {
 
-static constexpr uint32_t NTT_TILE_ELEMS = 2048;  // 64 KiB of Fr in LDS
+static constexpr uint32_t NTT_TILE_ELEMS = 1024;  // 32 KiB of Fr in LDS: 4-5 blocks per CU hide the load/store phases of each other
 static constexpr uint32_t NTT_THREADS = 256;
 
 template <bool DIF>
@@ -31,6 +31,46 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(Fr* __restrict__ data,
   const uint64_t col0 = (uint64_t)blockIdx.x * T;
   const bool col_major = Cq >= T;  // adjacent tile columns are adjacent in memory
 
+  if (col_major && T <= NTT_THREADS) {
+    // ---- fast path: a lane keeps ONE column for the whole pass, so the (64-bit) column -> address / twiddle-base
+    // arithmetic is done once per lane instead of once per element and butterfly ----
+    const uint32_t tc = threadIdx.x & (T - 1), jr = threadIdx.x / T, jstep = NTT_THREADS / T;
+    const uint64_t col = col0 + tc;
+    const bool valid = col < ncols;
+    const uint64_t bh = valid ? col / Cq : 0, q = valid ? col % Cq : 0;
+    const uint32_t base_low = (uint32_t)(q / P);
+    Fr* ptr = data + bh * G * Cq + q;
+    if (valid)
+      for (uint32_t j = jr; j < G; j += jstep) sh[j * T + tc] = ptr[(uint64_t)j * Cq];
+    __syncthreads();
+    for (uint32_t t = 0; t < lg; t++) {
+      const uint32_t half_l = DIF ? (G >> (t + 1)) : (1u << t);
+      const uint32_t mult_log = logn - 1 - (31 - __builtin_clz(half_l)) - (31 - __builtin_clz(stride));
+      if (valid)
+        for (uint32_t jj = jr; jj < G / 2; jj += jstep) {
+          const uint32_t lo = jj & (half_l - 1);
+          const uint32_t j = ((jj - lo) << 1) + lo;
+          const uint32_t e = (lo * stride + base_low) << mult_log;
+          Fr u = sh[j * T + tc];
+          Fr v = sh[(j + half_l) * T + tc];
+          if (DIF) {
+            sh[j * T + tc] = u + v;
+            Fr d = u - v;
+            sh[(j + half_l) * T + tc] = e ? d * tw[e] : d;
+          } else {
+            if (e) v = v * tw[e];
+            sh[j * T + tc] = u + v;
+            sh[(j + half_l) * T + tc] = u - v;
+          }
+        }
+      __syncthreads();
+    }
+    if (valid)
+      for (uint32_t j = jr; j < G; j += jstep) ptr[(uint64_t)j * Cq] = sh[j * T + tc];
+    return;
+  }
+
+  // ---- generic path (tiny transforms, or fewer contiguous columns than the tile is wide) ----
   // ---- load tile ----
   for (uint32_t idx = threadIdx.x; idx < G * T; idx += NTT_THREADS) {
     uint32_t j, tc;

@@ -56,10 +56,8 @@ inline Fq2 fq2_pow(const Fq2& base, const uint32_t* e, int nlimbs) {
     }
   return acc;
 }
-inline const PairingConsts& pairing_consts() {
-  static PairingConsts pc;
-  static bool ready = false;
-  if (ready) return pc;
+inline PairingConsts make_pairing_consts() {
+  PairingConsts pc;
   // (p-1)/6 as limbs: p-1 divided by 6
   uint32_t pm1[8];
   for (int i = 0; i < 8; i++) pm1[i] = FqParams::MOD(i);
@@ -84,7 +82,10 @@ inline const PairingConsts& pairing_consts() {
     pc.wfrob[k] = f12_mul(t, wk);
     gk = gk * g16;
   }
-  ready = true;
+  return pc;
+}
+inline const PairingConsts& pairing_consts() {
+  static const PairingConsts pc = make_pairing_consts();   // thread-safe one-time initialisation
   return pc;
 }
 inline Fq12 f12_frobenius(const Fq12& a) {

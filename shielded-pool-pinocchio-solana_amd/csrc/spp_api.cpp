@@ -427,6 +427,9 @@ bool parse_pk(const std::vector<uint8_t>& buf, PkFile& k) {
 }
 }  // namespace
 
+static void destroy_circuit(spp_circuit* c);
+static void free_workspace(Workspace& w);
+
 // merge `extra` into the entry of `wire` (or append one)
 template <class F>
 static void merge_point(std::vector<uint32_t>& wires, std::vector<Affine<F>>& pts, uint32_t wire, const Affine<F>& extra) {
@@ -447,16 +450,19 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
   spp_circuit* c = new spp_circuit();
   c->ctx = ctx;
   c->c_bits = (uint32_t)window_bits;
-  if (!c->circ.load(circuit_path)) { delete c; return fail(SPP_ERR_IO, "cannot read circuit %s", circuit_path); }
+  // every early return below releases what has been allocated so far
+  struct Guard {
+    spp_circuit* c;
+    ~Guard() { if (c) destroy_circuit(c); }
+  } guard{c};
+  if (!c->circ.load(circuit_path)) return fail(SPP_ERR_IO, "cannot read circuit %s", circuit_path);
   std::vector<uint8_t> pkbuf;
   PkFile pk;
-  if (!read_file(pk_path, pkbuf)) { delete c; return fail(SPP_ERR_IO, "cannot read proving key %s", pk_path); }
-  if (!parse_pk(pkbuf, pk)) { delete c; return fail(SPP_ERR_FORMAT, "malformed proving key %s", pk_path); }
+  if (!read_file(pk_path, pkbuf)) return fail(SPP_ERR_IO, "cannot read proving key %s", pk_path);
+  if (!parse_pk(pkbuf, pk)) return fail(SPP_ERR_FORMAT, "malformed proving key %s", pk_path);
   const Circuit& circ = c->circ;
-  if (pk.circuit_id != circ.id || pk.n_wires != circ.n_wires || pk.domain_log != circ.domain_log) {
-    delete c;
+  if (pk.circuit_id != circ.id || pk.n_wires != circ.n_wires || pk.domain_log != circ.domain_log)
     return fail(SPP_ERR_FORMAT, "proving key does not match the circuit");
-  }
   // window bits per MSM set: uniform when requested, otherwise a greedy split of the HBM budget (env
   // SPP_TABLE_BUDGET_GB, default 200, capped at 75 % of the free HBM): repeatedly widen the set whose next window bit
   // removes the most mixed-addition work per extra byte (one bit ~ -8 % additions, x2 table; a G2 addition is
@@ -673,6 +679,7 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
       HIP_TRY(hipEventCreate(&pr.second));
     }
   }
+  guard.c = nullptr;
   *out = c;
   return SPP_OK;
 }
@@ -682,7 +689,7 @@ static void free_workspace(Workspace& w) {
   w.owned.clear();
   w.cap = 0;
 }
-extern "C" void spp_free_circuit(spp_circuit* c) {
+static void destroy_circuit(spp_circuit* c) {
   if (!c) return;
   hipSetDevice(c->ctx->device);
   hipStreamSynchronize(c->ctx->stream);
@@ -690,11 +697,15 @@ extern "C" void spp_free_circuit(spp_circuit* c) {
     if (w.st) hipStreamSynchronize(w.st);
     free_workspace(w);
     for (auto& evt : w.ev) if (evt) hipEventDestroy(evt);
-    for (auto& pr : w.msm_ev) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    for (auto& pr : w.msm_ev) {
+      if (pr.first) hipEventDestroy(pr.first);
+      if (pr.second) hipEventDestroy(pr.second);
+    }
   }
   for (void* p : c->owned) hipFree(p);
   delete c;
 }
+extern "C" void spp_free_circuit(spp_circuit* c) { destroy_circuit(c); }
 extern "C" int spp_circuit_info(const spp_circuit* c, uint32_t info[8]) {
   if (!c || !info) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
   info[0] = c->circ.id; info[1] = c->circ.n_public - 1; info[2] = c->circ.n_secret; info[3] = c->circ.n_wires;
