@@ -402,3 +402,36 @@ def test_host_mirror_generate_proof_and_audit_proof(tmp_path, withdraw_artifacts
         assert toml.startswith('secret_key = "0x%064x"\nwa_commitment = ' % 12345) and "\nk1 = [" in toml      # generate_audit.py:630-641
     finally:
         del os.environ["SPP_TABLE_BUDGET_GB"]
+
+
+def test_extreme_inputs_and_empty_batch(withdraw_handle, withdraw_artifacts):
+    """Maximum sizes the circuit admits: amount 2^64-1, leaf index 65535 (all path bits set), secret key r-1 (254 bits,
+    top window of the Grumpkin ladder), siblings r-1; plus the empty batch."""
+    from oracle import native, groth16, hashes as H
+    from oracle.bn254 import R
+    sk = R - 1
+    owner = H.fixed_base_scalar_mul(sk)
+    amount = (1 << 64) - 1
+    rnd = R - 2
+    idx = (1 << 16) - 1
+    sib = [R - 1 - i for i in range(16)]
+    cm = H.poseidon_hash4(owner[0], owner[1], amount, rnd)
+    row = [H.compute_merkle_root(cm, idx, sib), H.poseidon_hash2(sk, idx), R - 1, amount, H.poseidon_hash2(owner[0], owner[1]),
+           sk, owner[0], owner[1], rnd, idx] + sib
+    proofs, pws, status = withdraw_handle.prove_batch([row], [(R - 1, R - 2)])     # extreme blinding too
+    assert status == [0]
+    orc = native.Prover(withdraw_artifacts["sppc"], withdraw_artifacts["pk"])
+    rc, proof, pw = orc.prove(row, R - 1, R - 2)
+    assert rc == 0 and proofs[0] == proof and pws[0] == pw
+    assert groth16.verify(open(withdraw_artifacts["vk"], "rb").read(), proofs[0], pws[0])
+    # blinding 0 (degenerate r = s = 0) still yields a valid proof
+    proofs0, pws0, st0 = withdraw_handle.prove_batch([row], [(0, 0)])
+    assert st0 == [0] and proofs0[0] == orc.prove(row, 0, 0)[1]
+    # empty batch: nothing to do, no error
+    assert withdraw_handle.prove_batch([], []) == ([], [], [])
+    # OS randomness: two proofs of the same statement differ and both verify
+    pa, wa_, sa = withdraw_handle.prove_batch([row, row], None)
+    assert sa == [0, 0] and pa[0] != pa[1]
+    import spp
+    vk = open(withdraw_artifacts["vk"], "rb").read()
+    assert spp.verify(vk, pa[0], wa_[0]) and spp.verify(vk, pa[1], wa_[1])
