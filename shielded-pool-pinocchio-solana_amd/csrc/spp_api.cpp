@@ -157,6 +157,8 @@ struct MsmBuf {
 };
 struct Workspace {
   hipStream_t st = nullptr;
+  hipStream_t st2 = nullptr;          // side stream: the G2 MSM only needs the witness, so it runs beside matrix eval / NTT / G1 MSMs
+  hipEvent_t ev_w = nullptr, ev_b2 = nullptr;
   size_t cap = 0, last_P = 0;
   Fr *W = nullptr, *abc = nullptr, *scratch = nullptr;
   G1Affine* commit_affine = nullptr;
@@ -672,6 +674,9 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
   for (int k = 0; k < 2; k++) {
     Workspace& w = c->ws[k];
     w.st = ctx->pstream[k];
+    HIP_TRY(hipStreamCreate(&w.st2));
+    HIP_TRY(hipEventCreateWithFlags(&w.ev_w, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&w.ev_b2, hipEventDisableTiming));
     for (auto& evt : w.ev) HIP_TRY(hipEventCreate(&evt));
     w.msm_ev.resize(8);
     for (auto& pr : w.msm_ev) {
@@ -695,6 +700,9 @@ static void destroy_circuit(spp_circuit* c) {
   hipStreamSynchronize(c->ctx->stream);
   for (auto& w : c->ws) {
     if (w.st) hipStreamSynchronize(w.st);
+    if (w.st2) { hipStreamSynchronize(w.st2); hipStreamDestroy(w.st2); }
+    if (w.ev_w) hipEventDestroy(w.ev_w);
+    if (w.ev_b2) hipEventDestroy(w.ev_b2);
     free_workspace(w);
     for (auto& evt : w.ev) if (evt) hipEventDestroy(evt);
     for (auto& pr : w.msm_ev) {
@@ -761,8 +769,8 @@ static int ensure_workspace(spp_circuit* c, Workspace& w, size_t P) {
 }
 
 template <class F>
-static void run_msm(spp_circuit* c, Workspace& w, const MsmSet<F>& s, MsmBuf<F>& b, uint32_t P, bool timed) {
-  hipStream_t st = w.st;
+static void run_msm(spp_circuit* c, Workspace& w, const MsmSet<F>& s, MsmBuf<F>& b, uint32_t P, bool timed, hipStream_t st_override = nullptr) {
+  hipStream_t st = st_override ? st_override : w.st;
   const Fr* scal = s.from_h ? w.abc : w.W;
   uint32_t S = msm_slices(s.N, P);
   while (S > 1 && (size_t)S * P > b.partial_cap) S--;  // never exceed the allocated partial buffer
@@ -797,6 +805,11 @@ static int prove_on_device(spp_circuit* c, Workspace& w, uint32_t P, const uint8
     }
   }
   hipEventRecord(w.ev[1], st);
+  // the G2 MSM depends on the witness only: start it now on the side stream
+  hipEventRecord(w.ev_w, st);
+  hipStreamWaitEvent(w.st2, w.ev_w, 0);
+  run_msm(c, w, c->B2, w.B2, P, false, w.st2);
+  hipEventRecord(w.ev_b2, w.st2);
   // 2. constraint evaluations + satisfaction check
   launch_spmv_check(st, c->dc, w.W, w.abc, n, P, d_status);
   hipEventRecord(w.ev[2], st);
@@ -816,7 +829,7 @@ static int prove_on_device(spp_circuit* c, Workspace& w, uint32_t P, const uint8
   run_msm(c, w, c->Z, w.Z, P, true);
   run_msm(c, w, c->CS, w.CS, P, true);
   hipEventRecord(w.ev[4], st);
-  run_msm(c, w, c->B2, w.B2, P, false);
+  hipStreamWaitEvent(st, w.ev_b2, 0);   // join the G2 MSM
   hipEventRecord(w.ev[5], st);
   // 5. assembly
   AssembleArgs a;
