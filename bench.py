@@ -209,7 +209,7 @@ def main():
                     "table_bytes": h.table_bytes, "parallelism": "independent proofs x%d" % world,
                     "pk_bcast_ms": round(bcast_ms, 3), "setup_s": round(setup_s, 2), "load_s": round(load_s, 2)},
                 "stage_ms_per_step": {k: round(v / steps, 3) for k, v in zip(
-                    ["solve+commit", "matrix_eval", "ntt_qap", "msm_g1", "msm_g2", "assemble", "total"], acc["stage"])},
+                    ["solve+commit", "matrix_eval", "ntt_qap", "msm_g1", "msm_g2_side_stream_join", "assemble", "total"], acc["stage"])},
                 "roofline": {"bound": "hbm", "kernel": "k_msm_fixed<Fq>", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "alg_bytes_per_launch": int(alg_bytes),
                              "avg_launch_ms": round(avg_ms, 4), "launches_timed": acc["kern_n"],

@@ -103,7 +103,8 @@ int spp_prove_batch_device(spp_circuit* c, size_t count, const void* d_inputs, c
                            void* d_status);
 int spp_sync(spp_circuit* c);
 /* per-stage device time of the last spp_prove_batch_device call, milliseconds:
- * [0] witness solve (+commitment), [1] matrix eval, [2] NTT/QAP, [3] MSM G1, [4] MSM G2, [5] assembly, [6] total;
+ * [0] witness solve (+commitment), [1] matrix eval, [2] NTT/QAP, [3] MSM G1, [4] wait for the G2 MSM (it runs on a side
+ * stream from the end of [0]), [5] assembly, [6] total;
  * [7] = average duration of one k_msm_fixed<G1> launch (the dominant kernel), [8] = number of such launches */
 int spp_last_timings(spp_circuit* c, float ms[9]);
 /* which = 0: the last enqueued batch, 1: the one before it (consecutive batches alternate between two streams,
