@@ -13,7 +13,10 @@
  *                             demo-frontend/app/lib/rlwe.ts:157-247
  *   spp_poseidon_*            client/merkle.ts:22-38,119-140,165-221 (circomlibjs Poseidon, Merkle tree)
  *   spp_grumpkin_keygen_batch client/merkle.ts:98-113 generateIdentityKeypair
- *   spp_msm_g1 / spp_ntt_fr   micro-benchmark entry points (BASELINE.json configs[4]); no reference equivalent
+ *   spp_audit_inputs_batch    scripts/generate_audit.py:468-641 (everything before `nargo execute`)
+ *   spp_verify                `sunspot verify` noir_circuit/prove_linux.sh:86-87, audit_circuit/prove_audit.sh:98-99
+ *   spp_shamir_reconstruct / spp_rlwe_decrypt_batch   scripts/rlwe_decrypt.py:61-132, demo-frontend/app/lib/shamir.ts:97-169
+ *   spp_msm_g1(_pippenger) / spp_ntt_fr   micro-benchmark entry points (BASELINE.json configs[4]); no reference equivalent
  *
  * Conventions: field elements cross the boundary as 32-byte big-endian canonical integers (the encoding
  * of the reference's .pw files, shielded_pool_program/src/instructions/withdraw.rs:74-90); points as
@@ -157,6 +160,16 @@ int spp_audit_inputs_batch(spp_ctx* ctx, const uint32_t* pk_a, const uint32_t* p
                            const int8_t* e1, const int8_t* e2, uint8_t* rows);
 int spp_audit_inputs_batch_device(spp_ctx* ctx, const void* d_pk_a, const void* d_pk_b, size_t count, const void* d_sk, const void* d_r,
                                   const void* d_e1, const void* d_e2, void* d_rows);
+
+/* ---- auditor side (scripts/rlwe_decrypt.py:61-132, demo-frontend/app/lib/shamir.ts:97-169) ---- */
+/* Shamir reconstruction at 0 over BN254 Fr for n coefficients from t shares: xs[t] share indices, ys = t * n * 32 B
+ * (share-major, big-endian). secret_be (optional): n * 32 B; sk_mod_q (optional): the centred value reduced mod q
+ * (reconstructSk, shamir.ts:97-120). */
+int spp_shamir_reconstruct(spp_ctx* ctx, uint32_t t, const uint32_t* xs, const uint8_t* ys, size_t n, uint8_t* secret_be,
+                           uint32_t* sk_mod_q);
+/* rlweDecrypt (shamir.ts:134-169 / rlwe_decrypt.py:106-132) for `count` ciphertexts: c0 count*64, c1 count*1024 in
+ * [0,q); msg = count * 64 recovered byte slots (owner_x = slots 0..31 little-endian, owner_y = slots 32..63). */
+int spp_rlwe_decrypt_batch(spp_ctx* ctx, const uint32_t* sk_mod_q, size_t count, const uint32_t* c0, const uint32_t* c1, uint8_t* msg);
 
 /* ---- micro-benchmark / unit entry points ---- */
 /* data: n = 2^logn elements, 32 B big-endian each, natural order in and out */

@@ -53,6 +53,9 @@ void launch_fr_from_be(hipStream_t st, const uint8_t* in, Fr* out, uint32_t n);
 void launch_fr_to_be(hipStream_t st, const Fr* in, uint8_t* out, uint32_t n);
 void launch_grumpkin_keygen(hipStream_t st, const GkAffine* table, const uint8_t* sk_be, uint8_t* xy_be, uint32_t count);
 void launch_poseidon2_sponge(hipStream_t st, HashConsts hc, const uint8_t* in_be, uint32_t n, uint8_t* out_be, uint32_t count);
+void launch_rlwe_decrypt(hipStream_t st, const uint32_t* sk_mod_q, const uint32_t* c0, const uint32_t* c1, uint8_t* msg, uint32_t count);
+void launch_shamir_combine(hipStream_t st, const Fr* lambda, const uint8_t* ys_be, uint32_t t, uint32_t n, uint8_t* secret_be,
+                           uint32_t* sk_mod_q);
 void launch_audit_msg(hipStream_t st, const uint8_t* xy_be, uint8_t* msg, uint32_t count);
 void launch_audit_assemble(hipStream_t st, const uint8_t* wa_be, const uint8_t* ct_be, const uint8_t* packed_be, const uint8_t* sk_be,
                            const int8_t* r, const int8_t* e1, const int8_t* e2, const int32_t* k0, const int32_t* k1, uint8_t* rows,

@@ -312,6 +312,68 @@ void launch_poseidon2_sponge(hipStream_t st, HashConsts hc, const uint8_t* in_be
 
 
 // ----------------------------------------------------------------------------------------------------
+// Auditor side: scripts/rlwe_decrypt.py:61-132, demo-frontend/app/lib/shamir.ts:97-169
+// ----------------------------------------------------------------------------------------------------
+// msg[i] = round(centered((c0 + sk*c1 mod (X^n+1, q))[i]) / Delta) mod 256 for the 64 message slots; one 64-lane block per
+// ciphertext, lane i owns slot i:  (sk*c1)[i] = sum_j SK2[(i - j) mod 2048] * c1[j],  SK2 = [sk, (q - sk) mod q].
+// Products are 28 x 28 bits: the 64-bit accumulator is folded mod q every 128 terms.
+__global__ void __launch_bounds__(64) k_rlwe_decrypt(const uint32_t* __restrict__ sk_mod_q, const uint32_t* __restrict__ c0,
+                                                     const uint32_t* __restrict__ c1, uint8_t* __restrict__ msg, uint32_t count) {
+  __shared__ uint32_t SK2[2 * RL_N];
+  __shared__ uint32_t cs[RL_N];
+  const uint32_t inst = blockIdx.x, t = threadIdx.x;
+  if (inst >= count) return;
+  for (int i = t; i < RL_N; i += 64) {
+    const uint32_t s = sk_mod_q[i];
+    SK2[i] = s;
+    SK2[RL_N + i] = s ? (uint32_t)RL_Q - s : 0u;
+    cs[i] = c1[(size_t)inst * RL_N + i];
+  }
+  __syncthreads();
+  unsigned long long acc = 0, total = 0;
+  for (int j = 0; j < RL_N; j++) {
+    acc += (unsigned long long)SK2[(t - j) & 2047] * cs[j];
+    if ((j & 127) == 127) { total += acc % (unsigned long long)RL_Q; acc = 0; }
+  }
+  const long long skc1 = (long long)(total % (unsigned long long)RL_Q);
+  long long noisy = ((long long)c0[(size_t)inst * RL_SLOTS + t] + skc1) % RL_Q;
+  if (noisy > RL_Q / 2) noisy -= RL_Q;                       // centered_mod (rlwe_decrypt.py:54-58)
+  long long k = noisy / RL_DELTA, rem = noisy % RL_DELTA;    // floor division
+  if (rem < 0) { rem += RL_DELTA; k -= 1; }
+  if (2 * rem > RL_DELTA || (2 * rem == RL_DELTA && (k & 1))) k += 1;   // Python round(): half to even
+  msg[(size_t)inst * RL_SLOTS + t] = (uint8_t)(((k % 256) + 256) % 256);
+}
+void launch_rlwe_decrypt(hipStream_t st, const uint32_t* sk_mod_q, const uint32_t* c0, const uint32_t* c1, uint8_t* msg, uint32_t count) {
+  if (count) hipLaunchKernelGGL(k_rlwe_decrypt, dim3(count), dim3(64), 0, st, sk_mod_q, c0, c1, msg, count);
+}
+
+// Shamir reconstruction at 0: out[k] = sum_i lambda_i * y[i][k] over Fr, then centred and reduced mod q (shamir.ts:97-120)
+__global__ void __launch_bounds__(256) k_shamir_combine(const Fr* __restrict__ lambda, const uint8_t* __restrict__ ys_be, uint32_t t,
+                                                        uint32_t n, uint8_t* __restrict__ secret_be, uint32_t* __restrict__ sk_mod_q) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  Fr acc = Fr::zero();
+  for (uint32_t i = 0; i < t; i++) acc = acc + lambda[i] * load_be(ys_be + ((size_t)i * n + k) * 32);
+  if (secret_be) store_be(secret_be + (size_t)k * 32, acc);
+  if (sk_mod_q) {
+    uint32_t c[8];
+    acc.to_canonical(c);
+    // centred value must be small (|v| < 2^31) for a key coefficient; larger values are reduced limb-wise
+    const bool neg = canonical_gt_half<FrParams>(c);
+    uint32_t m[8];
+    if (neg) canonical_negate<FrParams>(c, m);
+    else { SPP_UNROLL for (int i = 0; i < 8; i++) m[i] = c[i]; }
+    unsigned long long r = 0;   // |v| mod q by Horner over the limbs
+    for (int i = 7; i >= 0; i--) r = ((r << 32) | m[i]) % (unsigned long long)RL_Q;
+    sk_mod_q[k] = neg ? (r ? (uint32_t)(RL_Q - (long long)r) : 0u) : (uint32_t)r;
+  }
+}
+void launch_shamir_combine(hipStream_t st, const Fr* lambda, const uint8_t* ys_be, uint32_t t, uint32_t n, uint8_t* secret_be,
+                           uint32_t* sk_mod_q) {
+  if (n) hipLaunchKernelGGL(k_shamir_combine, dim3((n + 255) / 256), dim3(256), 0, st, lambda, ys_be, t, n, secret_be, sk_mod_q);
+}
+
+// ----------------------------------------------------------------------------------------------------
 // audit input assembly: (sk, r, e1, e2) -> the 3360-field input row of the audit circuit, all on the device
 // (scripts/generate_audit.py:468-641: keygen, message slots, encryption + quotients, packing, commitments, Prover.toml)
 // ----------------------------------------------------------------------------------------------------

@@ -1670,3 +1670,61 @@ extern "C" int spp_audit_inputs_batch(spp_ctx* ctx, const uint32_t* pk_a, const 
   HIP_TRY(hipMemcpy(rows, drows.p, count * 3360 * 32, hipMemcpyDeviceToHost));
   return SPP_OK;
 }
+
+// -----------------------------------------------------------------------------------------------------
+// auditor side: Shamir reconstruction of the RLWE secret key, batch decryption of audit ciphertexts
+// -----------------------------------------------------------------------------------------------------
+extern "C" int spp_shamir_reconstruct(spp_ctx* ctx, uint32_t t, const uint32_t* xs, const uint8_t* ys, size_t n, uint8_t* secret_be,
+                                      uint32_t* sk_mod_q) {
+  if (!ctx || !xs || !ys || (!secret_be && !sk_mod_q)) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  if (t == 0 || t > 64) return fail(SPP_ERR_BAD_INPUT, "threshold out of range");
+  for (uint32_t i = 0; i < t; i++)
+    for (uint32_t j = 0; j < i; j++)
+      if (xs[i] == xs[j]) return fail(SPP_ERR_BAD_INPUT, "duplicate share index");
+  if (n == 0) return SPP_OK;
+  // Lagrange coefficients at 0: lambda_i = prod_{j != i} (-x_j) / (x_i - x_j)   (rlwe_decrypt.py:38-51)
+  std::vector<Fr> lam(t);
+  for (uint32_t i = 0; i < t; i++) {
+    Fr num = Fr::one(), den = Fr::one();
+    for (uint32_t j = 0; j < t; j++) {
+      if (i == j) continue;
+      num = num * Fr::from_u64(xs[j]).neg();
+      den = den * (Fr::from_u64(xs[i]) - Fr::from_u64(xs[j]));
+    }
+    lam[i] = num * den.inv();
+  }
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  DevBuf dl, dy, ds, dq;
+  UP(dl, lam.data(), sizeof(Fr) * t);
+  UP(dy, ys, (size_t)t * n * 32);
+  if (secret_be) HIP_TRY(ds.alloc(n * 32));
+  if (sk_mod_q) HIP_TRY(dq.alloc(n * 4));
+  launch_shamir_combine(st, dl.as<Fr>(), dy.as<uint8_t>(), t, (uint32_t)n, secret_be ? ds.as<uint8_t>() : nullptr,
+                        sk_mod_q ? dq.as<uint32_t>() : nullptr);
+  if (secret_be) HIP_TRY(hipMemcpyAsync(secret_be, ds.p, n * 32, hipMemcpyDeviceToHost, st));
+  if (sk_mod_q) HIP_TRY(hipMemcpyAsync(sk_mod_q, dq.p, n * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipGetLastError());
+  return SPP_OK;
+}
+
+extern "C" int spp_rlwe_decrypt_batch(spp_ctx* ctx, const uint32_t* sk_mod_q, size_t count, const uint32_t* c0, const uint32_t* c1,
+                                      uint8_t* msg) {
+  if (!ctx || !sk_mod_q || !c0 || !c1 || !msg) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  if (count == 0) return SPP_OK;
+  for (int i = 0; i < 1024; i++)
+    if (sk_mod_q[i] >= 167772161u) return fail(SPP_ERR_BAD_INPUT, "secret key coefficient not in [0, q)");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  DevBuf dsk, d0, d1, dm;
+  UP(dsk, sk_mod_q, 4096); UP(d0, c0, count * 64 * 4); UP(d1, c1, count * 1024 * 4);
+  HIP_TRY(dm.alloc(count * 64));
+  launch_rlwe_decrypt(st, dsk.as<uint32_t>(), d0.as<uint32_t>(), d1.as<uint32_t>(), dm.as<uint8_t>(), (uint32_t)count);
+  HIP_TRY(hipMemcpyAsync(msg, dm.p, count * 64, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipGetLastError());
+  return SPP_OK;
+}

@@ -125,3 +125,28 @@ def audit_input_rows(ctx, pk_a, pk_b, secret_keys, r, e1, e2):
     p = lambda x: x.ctypes.data_as(ctypes.c_void_p)
     check(ctx.L.spp_audit_inputs_batch(ctx.h, p(a), p(b), count, _be(secret_keys), p(r), p(e1), p(e2), p(rows)))
     return [_unbe(rows[i].tobytes(), 3360) for i in range(count)]
+
+
+# ---- auditor side: demo-frontend/app/lib/shamir.ts reconstructSk / rlweDecrypt, scripts/rlwe_decrypt.py ----
+def reconstruct_sk(ctx, shares):
+    """shares: list of {"x": int, "y": [hex or int] * 1024} (threshold = len(shares)); returns sk mod q (list of ints)."""
+    t = len(shares)
+    n = len(shares[0]["y"])
+    xs = (ctypes.c_uint32 * t)(*[int(s["x"]) for s in shares])
+    ys = _be((int(v, 16) if isinstance(v, str) else int(v)) for s in shares for v in s["y"])
+    out = (ctypes.c_uint32 * n)()
+    check(ctx.L.spp_shamir_reconstruct(ctx.h, t, ctypes.cast(xs, ctypes.c_void_p), ys, n, None, ctypes.cast(out, ctypes.c_void_p)))
+    return list(out)
+
+
+def rlwe_decrypt(ctx, sk_mod_q, c0, c1):
+    """Batch: c0 [count,64], c1 [count,1024] -> list of (owner_x, owner_y) and the raw byte slots."""
+    c0 = np.ascontiguousarray(c0, dtype=np.uint32).reshape(-1, MSG_SLOTS)
+    count = c0.shape[0]
+    c1 = np.ascontiguousarray(c1, dtype=np.uint32).reshape(count, RLWE_N)
+    sk = np.ascontiguousarray(sk_mod_q, dtype=np.uint32)
+    msg = np.zeros((count, MSG_SLOTS), dtype=np.uint8)
+    p = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+    check(ctx.L.spp_rlwe_decrypt_batch(ctx.h, p(sk), count, p(c0), p(c1), p(msg)))
+    owners = [(int.from_bytes(msg[i, :32].tobytes(), "little"), int.from_bytes(msg[i, 32:].tobytes(), "little")) for i in range(count)]
+    return owners, msg

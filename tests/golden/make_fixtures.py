@@ -74,6 +74,29 @@ def main():
     with open(os.path.join(HERE, "rlwe_vectors.json"), "w") as f:
         json.dump(vectors, f)
 
+    # auditor side (scripts/rlwe_decrypt.py): Shamir shares 1+2 (data files of the reference) -> sk, decrypt every vector
+    rd = load_ref("rlwe_decrypt")
+    shares = []
+    for idx in (1, 2, 3):
+        d = json.load(open(os.path.join(REF, "demo-frontend", "public", "rlwe", "rlwe_sk_shares", "share_%d.json" % idx)))
+        shares.append({"share_index": d["share_index"], "threshold": d["threshold"], "x": d["coefficients"][0]["x"],
+                       "y": [c["y"] for c in d["coefficients"]]})
+    sk_q = []
+    for k in range(N):
+        v = rd.shamir_reconstruct_field([(shares[0]["x"], int(shares[0]["y"][k], 16)), (shares[1]["x"], int(shares[1]["y"][k], 16))], 2)
+        sk_q.append(rd.centered_mod(v, rd.BN254_P) % Q)
+    dec = []
+    for v in vectors:
+        sk_c1 = rd.negacyclic_mul_mod_q(sk_q, v["c1"], N, Q)
+        msg = []
+        for i in range(SLOTS):
+            noisy = rd.centered_mod((v["c0"][i] + sk_c1[i]) % Q, Q)
+            msg.append(round(noisy / rd.DELTA) % 256)
+        assert msg == v["msg"], v["name"]
+        dec.append({"name": v["name"], "sk_c1_head": sk_c1[:8], "msg": msg})
+    with open(os.path.join(HERE, "rlwe_decrypt.json"), "w") as f:
+        json.dump({"shares": shares[:2], "share3_y_head": shares[2]["y"][:4], "share3_x": shares[2]["x"], "sk_mod_q": sk_q, "decrypt": dec}, f)
+
     with open(os.path.join(HERE, "pack_kat.json"), "w") as f:
         json.dump({"in": list(range(1, 9)), "out": [hex(v) for v in ga.pack_values(list(range(1, 9)))],
                    "bytes_in": hex(0x0102030405), "bytes_out": ga.encode_field_to_bytes(0x0102030405, 8),

@@ -435,3 +435,27 @@ def test_extreme_inputs_and_empty_batch(withdraw_handle, withdraw_artifacts):
     import spp
     vk = open(withdraw_artifacts["vk"], "rb").read()
     assert spp.verify(vk, pa[0], wa_[0]) and spp.verify(vk, pa[1], wa_[1])
+
+
+def test_auditor_side_reconstruct_and_decrypt(ctx, rlwe_pk, rlwe_vectors):
+    """scripts/rlwe_decrypt.py end to end on the GPU against the reference-derived fixture (tests/golden/rlwe_decrypt.json):
+    Shamir shares 1+2 -> sk mod q, every fixture ciphertext decrypts to its message; plus random ciphertexts vs the oracle."""
+    import json
+    import numpy as np
+    from conftest import GOLDEN
+    from spp import witness
+    from oracle import rlwe, hashes as H
+    d = json.load(open(os.path.join(GOLDEN, "rlwe_decrypt.json")))
+    sk = witness.reconstruct_sk(ctx, d["shares"])
+    assert sk == d["sk_mod_q"]
+    owners, msg = witness.rlwe_decrypt(ctx, sk, [v["c0"] for v in rlwe_vectors], [v["c1"] for v in rlwe_vectors])
+    for i, v in enumerate(rlwe_vectors):
+        assert msg[i].tolist() == v["msg"] == d["decrypt"][i]["msg"], v["name"]
+    assert owners[0] == H.fixed_base_scalar_mul(12345)          # RLWE-1 encrypts the key of sk = 12345 (generate_audit.py:470)
+    rng = np.random.default_rng(11)
+    c0 = rng.integers(0, rlwe.RLWE_Q, size=(33, 64), dtype=np.uint32)
+    c1 = rng.integers(0, rlwe.RLWE_Q, size=(33, 1024), dtype=np.uint32)
+    skr = rng.integers(0, rlwe.RLWE_Q, size=1024, dtype=np.uint32)    # arbitrary (not small) key: exercises the mod-q folding
+    _, got = witness.rlwe_decrypt(ctx, skr, c0, c1)
+    for i in (0, 7, 32):
+        assert got[i].tolist() == rlwe.rlwe_decrypt(skr.tolist(), c0[i].tolist(), c1[i].tolist())

@@ -106,3 +106,17 @@ def test_pairing_and_hash_to_field_kats():
     # RFC 9380 K.1 expand_message_xmd(SHA-256), msg = "", len 0x20
     assert B.expand_message_xmd(b"", b"QUUX-V01-CS02-with-expander-SHA256-128", 0x20).hex() == \
         "68a985b87eb6b46952128911f2a4412bbc302a9d759667f87f7a21d803f07235"
+
+
+def test_auditor_side_oracle(rlwe_vectors):
+    """Oracle restatement of scripts/rlwe_decrypt.py against the fixture generated by importing it."""
+    from oracle import rlwe
+    d = json.load(open(os.path.join(GOLDEN, "rlwe_decrypt.json")))
+    sk = rlwe.reconstruct_sk([s["x"] for s in d["shares"]], [[int(y, 16) for y in s["y"]] for s in d["shares"]])
+    assert sk == d["sk_mod_q"] and all(v in (0, 1, 2, 3) or v >= rlwe.RLWE_Q - 3 for v in sk)     # noise-bounded key
+    for v, e in zip(rlwe_vectors, d["decrypt"]):
+        m = rlwe.rlwe_decrypt(sk, v["c0"], v["c1"])
+        assert m == e["msg"] == v["msg"]
+        assert rlwe.decode_owner(m) == (sum(b << (8 * i) for i, b in enumerate(v["msg"][:32])), sum(b << (8 * i) for i, b in enumerate(v["msg"][32:])))
+    # rounding: exact ties go to the even neighbour, as Python's round()
+    assert [round(x / 2) for x in (1, 3, 5, -1, -3)] == [0, 2, 2, 0, -2]
