@@ -1,0 +1,303 @@
+// f29.hpp -- BN254 field elements in an unsaturated 9 x 29-bit limb form for the MSM / NTT inner loops (host + gfx950).
+//
+// Fp (bn254.hpp) keeps 8 saturated 32-bit words in memory and re-slices both operands into 29-bit limbs for every
+// product (and packs the result back): ~130 of the ~300 instructions of a multiplication are that re-slicing and the
+// carry chains of the surrounding add/sub.  F29 stays in the 29-bit form between operations:
+//   * value = sum l[k] * 2^(29k); limbs 0..7 are "normalised" when < 2^29, limb 8 carries whatever is left
+//     (values here stay below 2^257, so it never exceeds 2^25);
+//   * Montgomery radix R' = 2^261 (nine reduction steps of 29 bits): a product of values < 8p reduces to < 1.4 p, so
+//     nothing is ever compared against p;
+//   * subtraction adds a multiple of p whose limbs are pre-lifted above the subtrahend's (Pm::SUBC_kP_m: k*p with
+//     every low limb >= m*(2^29-1)), so limbs never go negative and no borrow chain exists; the carry sweep that
+//     brings limbs back under 2^29 is fused into the same pass where the result feeds a squaring;
+//   * unsigned 64-bit column sums: 9 * A * B + 9 * 2^58 + carries < 2^64 needs A * B <= 1.5 * 2^60 for the limb
+//     bounds A, B of the two operands -- every call site below states its bounds; tests/test_host_cpu.py re-derives
+//     them by interval arithmetic (tests/host/f29_bounds.py) and tests/host/field_check.cpp checks the arithmetic
+//     against Fp on random and extremal inputs.
+// Reference behaviour served: the G1/G2 multi-scalar multiplications and NTTs of `sunspot prove`
+// (noir_circuit/prove_linux.sh:83, scripts/generate_audit.py:680); the algorithm restated by oracle/c/groth16.c.
+#pragma once
+#include "bn254.hpp"
+
+namespace spp {
+
+template <class Pm>
+struct F29 {
+  uint32_t l[9];
+  using Base = Fp<Pm>;
+  typedef uint32_t (*ConstFn)(int);
+  static constexpr uint32_t M = (1u << 29) - 1u;
+  static constexpr uint32_t INV = Pm::INV32 & M;   // -p^-1 mod 2^29
+  static SPP_HD constexpr uint32_t P9(int k) { return Base::P9(k); }
+
+  template <ConstFn C>
+  static SPP_HD F29 konst() {
+    F29 r;
+    SPP_UNROLL for (int i = 0; i < 9; i++) r.l[i] = C(i);
+    return r;
+  }
+  // the same integer as 8 x 32-bit words (no domain change); words must be < 2^256
+  static SPP_HD F29 from_words(const uint32_t w[8]) {
+    F29 r;
+    Base::to9(w, r.l);
+    return r;
+  }
+  // normalised limbs, value < 2^256 -> 8 x 32-bit words
+  SPP_HD void to_words(uint32_t w[8]) const {
+    SPP_UNROLL for (int k = 0; k < 8; k++) {
+      const int bit = 32 * k, i = bit / 29, o = bit % 29;
+      uint32_t v = l[i] >> o;
+      if (i + 1 < 9) v |= l[i + 1] << (29 - o);
+      if (i + 2 < 9 && 58 - o < 32) v |= l[i + 2] << (58 - o);
+      w[k] = v;
+    }
+  }
+  // carry sweep: limbs 0..7 < 2^29 afterwards (input limbs < 2^32, value unchanged)
+  SPP_HD F29 norm() const {
+    F29 r;
+    uint32_t carry = 0;
+    SPP_UNROLL for (int k = 0; k < 8; k++) {
+      const uint32_t t = l[k] + carry;
+      r.l[k] = t & M;
+      carry = t >> 29;
+    }
+    r.l[8] = l[8] + carry;
+    return r;
+  }
+
+  // ---- column products -----------------------------------------------------------------------------
+  static SPP_HD void clear(uint64_t (&c)[18]) {
+    SPP_UNROLL for (int k = 0; k < 18; k++) c[k] = 0;
+  }
+  static SPP_HD void mac(uint64_t (&c)[18], const F29& a, const F29& b) {
+    SPP_UNROLL for (int i = 0; i < 9; i++) {
+      SPP_UNROLL for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)a.l[i] * b.l[j];
+    }
+  }
+  static SPP_HD void mac_sqr(uint64_t (&c)[18], const F29& a) {   // limbs of a < 2^31 (doubled in 32 bits)
+    uint32_t d[9];
+    SPP_UNROLL for (int i = 0; i < 9; i++) d[i] = a.l[i] << 1;
+    SPP_UNROLL for (int i = 0; i < 9; i++) {
+      c[2 * i] += (uint64_t)a.l[i] * a.l[i];
+      SPP_UNROLL for (int j = i + 1; j < 9; j++) c[i + j] += (uint64_t)a.l[i] * d[j];
+    }
+  }
+  // Montgomery reduction by R' = 2^261: nine steps clear 29 bits each; result normalised, < columns/R' + p
+  static SPP_HD F29 reduce(uint64_t (&c)[18]) {
+    SPP_UNROLL for (int k = 0; k < 9; k++) {
+      const uint32_t m = ((uint32_t)c[k] * INV) & M;
+      SPP_UNROLL for (int j = 0; j < 9; j++) c[k + j] += (uint64_t)m * P9(j);
+      c[k + 1] += c[k] >> 29;
+    }
+    F29 r;
+    SPP_UNROLL for (int k = 0; k < 8; k++) {
+      r.l[k] = (uint32_t)c[9 + k] & M;
+      c[10 + k] += c[9 + k] >> 29;
+    }
+    r.l[8] = (uint32_t)c[17];
+    return r;
+  }
+  friend SPP_HD F29 operator*(const F29& a, const F29& b) {
+    uint64_t c[18];
+    clear(c);
+    mac(c, a, b);
+    return reduce(c);
+  }
+  SPP_HD F29 sqr() const {
+    uint64_t c[18];
+    clear(c);
+    mac_sqr(c, *this);
+    return reduce(c);
+  }
+  // a*b + c*d with one reduction (limb bounds: 9*(A*B + C*D) + 9*2^58 < 2^64)
+  static SPP_HD F29 mul2(const F29& a, const F29& b, const F29& cc, const F29& d) {
+    uint64_t c[18];
+    clear(c);
+    mac(c, a, b);
+    mac(c, cc, d);
+    return reduce(c);
+  }
+
+  // ---- additive operations (C = lifted multiple of p; see gen_consts.py `lifted`) ---------------------
+  // a - b + C, limbs left as they fall (each < a + C)
+  template <ConstFn C>
+  static SPP_HD F29 sub_lazy(const F29& a, const F29& b) {
+    F29 r;
+    SPP_UNROLL for (int k = 0; k < 9; k++) r.l[k] = a.l[k] + (C(k) - b.l[k]);
+    return r;
+  }
+  template <ConstFn C>
+  static SPP_HD F29 neg_lazy(const F29& b) {
+    F29 r;
+    SPP_UNROLL for (int k = 0; k < 9; k++) r.l[k] = C(k) - b.l[k];
+    return r;
+  }
+  // a - b + C with the carry sweep fused in
+  template <ConstFn C>
+  static SPP_HD F29 sub_norm(const F29& a, const F29& b) {
+    F29 r;
+    uint32_t carry = 0;
+    SPP_UNROLL for (int k = 0; k < 8; k++) {
+      const uint32_t t = a.l[k] - b.l[k] + C(k) + carry;
+      r.l[k] = t & M;
+      carry = t >> 29;
+    }
+    r.l[8] = a.l[8] - b.l[8] + C(8) + carry;
+    return r;
+  }
+  // a - b - 2c + C, normalised
+  template <ConstFn C>
+  static SPP_HD F29 sub3_norm(const F29& a, const F29& b, const F29& c2) {
+    F29 r;
+    uint32_t carry = 0;
+    SPP_UNROLL for (int k = 0; k < 8; k++) {
+      const uint32_t t = a.l[k] - b.l[k] - (c2.l[k] << 1) + C(k) + carry;
+      r.l[k] = t & M;
+      carry = t >> 29;
+    }
+    r.l[8] = a.l[8] - b.l[8] - (c2.l[8] << 1) + C(8) + carry;
+    return r;
+  }
+  friend SPP_HD F29 add_lazy(const F29& a, const F29& b) {
+    F29 r;
+    SPP_UNROLL for (int k = 0; k < 9; k++) r.l[k] = a.l[k] + b.l[k];
+    return r;
+  }
+  friend SPP_HD F29 add_norm(const F29& a, const F29& b) {
+    F29 r;
+    uint32_t carry = 0;
+    SPP_UNROLL for (int k = 0; k < 8; k++) {
+      const uint32_t t = a.l[k] + b.l[k] + carry;
+      r.l[k] = t & M;
+      carry = t >> 29;
+    }
+    r.l[8] = a.l[8] + b.l[8] + carry;
+    return r;
+  }
+
+  // normalised value == k*p for some 0 <= k <= kmax ?  (normalised form is unique, so this is a limb comparison;
+  // the low limb filters out all but ~kmax/2^29 of the non-zero cases)
+  SPP_HD bool is_zero_mod_p(uint32_t kmax) const {
+    bool hit = false;
+    uint32_t lo = 0;
+    for (uint32_t k = 0; k <= kmax; k++) {
+      hit |= (l[0] == lo);
+      lo = (lo + P9(0)) & M;
+    }
+    if (!hit) return false;
+    uint32_t kp[9];
+    SPP_UNROLL for (int i = 0; i < 9; i++) kp[i] = 0;
+    for (uint32_t k = 0; k <= kmax; k++) {
+      uint32_t diff = 0;
+      SPP_UNROLL for (int i = 0; i < 9; i++) diff |= l[i] ^ kp[i];
+      if (diff == 0) return true;
+      uint32_t carry = 0;
+      SPP_UNROLL for (int i = 0; i < 8; i++) {
+        const uint32_t t = kp[i] + P9(i) + carry;
+        kp[i] = t & M;
+        carry = t >> 29;
+      }
+      kp[8] += P9(8) + carry;
+    }
+    return false;
+  }
+
+  // ---- domain changes ---------------------------------------------------------------------------------
+  // Fp (x*R, words) -> x*R'
+  static SPP_HD F29 from_fp(const Base& a) { return from_words(a.l) * konst<Pm::K29_IN>(); }
+  // x*R' (value < 8p) -> Fp in [0, 2p)
+  SPP_HD Base to_fp() const {
+    uint32_t w[8];
+    SPP_UNROLL for (int i = 0; i < 8; i++) w[i] = Pm::ONE(i);
+    const F29 t = *this * from_words(w);   // x*R' * R / R' = x*R, < 1.05 p
+    Base r;
+    t.to_words(r.l);
+    return r;
+  }
+  // zz*R'^2/R (the scaled domain of XYZZ29::ZZ/ZZZ) -> Fp
+  SPP_HD Base scaled_to_fp() const {
+    const F29 t = *this * konst<Pm::K29_ZZ_OUT>();
+    Base r;
+    t.to_words(r.l);
+    return r;
+  }
+};
+
+// --------------------------------------------------------------------------------------------------------------
+// XYZZ accumulator over F29 for "acc += table point" (mixed addition, 8M + 2S with 9 reductions).
+//   X, Y      : x*R', y*R'                     (X normalised < 5.1 p, Y < 1.2 p)
+//   ZZ, ZZZ   : zz*R'^2/R, zzz*R'^2/R          (< 1.1 p): a table coordinate x2*R (plain Fp words, < 2p) times ZZ
+//               gives x2*zz*R' directly, so the table stays in the Fp format every other kernel uses.
+// Limb/value bounds per line are in the comments (A x B = limb bounds of the two mul operands, in units of 2^29).
+// --------------------------------------------------------------------------------------------------------------
+template <class Pm>
+struct XYZZ29 {
+  using F = F29<Pm>;
+  using B = Fp<Pm>;
+  F X, Y, ZZ, ZZZ;
+  bool inf;
+
+  static SPP_HD XYZZ29 infinity() {
+    XYZZ29 r;
+    SPP_UNROLL for (int i = 0; i < 9; i++) r.X.l[i] = r.Y.l[i] = r.ZZ.l[i] = r.ZZZ.l[i] = 0;
+    r.inf = true;
+    return r;
+  }
+  SPP_HD XYZZ<B> to_xyzz() const {
+    if (inf) return XYZZ<B>::infinity();
+    return {X.to_fp(), Y.to_fp(), ZZ.scaled_to_fp(), ZZZ.scaled_to_fp()};
+  }
+  static SPP_HD XYZZ29 from_xyzz(const XYZZ<B>& q) {
+    XYZZ29 r;
+    r.inf = q.is_inf();
+    if (r.inf) return infinity();
+    r.X = F::from_fp(q.X);
+    r.Y = F::from_fp(q.Y);
+    // zz*R -> zz*R' -> zz*R'^2/R (K29_IN as a plain factor); rare path (doubling fallback)
+    r.ZZ = F::from_fp(q.ZZ) * F::template konst<Pm::K29_IN>();
+    r.ZZZ = F::from_fp(q.ZZZ) * F::template konst<Pm::K29_IN>();
+    return r;
+  }
+
+  // this += (x2, +-y2); e = table entry (Fp words, not infinity)
+  SPP_HD void madd(const Affine<B>& e, bool negate) {
+    F x2 = F::from_words(e.x.l);                                         // limbs < 1, value < 2p
+    F y2 = F::from_words(e.y.l);
+    if (negate) y2 = F::template neg_lazy<Pm::SUBC_4P_1>(y2);            // limbs < 2 (2^30), value <= 4p
+    if (inf) {
+      X = x2 * F::template konst<Pm::K29_IN>();
+      Y = y2 * F::template konst<Pm::K29_IN>();
+      ZZ = F::template konst<Pm::K29_IN>();
+      ZZZ = ZZ;
+      inf = false;
+      return;
+    }
+    const F U2 = x2 * ZZ;                                                // 1 x 1
+    const F S2 = y2 * ZZZ;                                               // 2 x 1
+    const F Pp = F::template sub_norm<Pm::SUBC_6P_1>(U2, X);             // normalised, < 7.1 p
+    const F Rr = F::template sub_norm<Pm::SUBC_2P_1>(S2, Y);             // normalised, < 3.1 p
+    if (Pp.is_zero_mod_p(7)) {
+      if (Rr.is_zero_mod_p(3)) {
+        XYZZ<B> t = to_xyzz();
+        t.dbl_inplace();
+        *this = from_xyzz(t);
+      } else {
+        *this = infinity();
+      }
+      return;
+    }
+    const F PP = Pp.sqr();                                               // 1 x 1 -> < 1.3 p
+    const F PPP = Pp * PP;                                               // < 1.06 p
+    const F Q = X * PP;                                                  // < 1.05 p
+    const F R2 = Rr.sqr();                                               // < 1.06 p
+    const F X3 = F::template sub3_norm<Pm::SUBC_4P_3>(R2, PPP, Q);       // normalised, < 5.1 p
+    const F T = F::template sub_lazy<Pm::SUBC_6P_1>(Q, X3);              // limbs < 3, < 7.1 p
+    const F Yn = F::template neg_lazy<Pm::SUBC_2P_1>(Y);                 // limbs < 2, <= 2p
+    Y = F::mul2(Rr, T, Yn, PPP);                                         // 1x3 + 2x1 -> < 1.2 p
+    ZZ = ZZ * PP;
+    ZZZ = ZZZ * PPP;
+    X = X3;
+  }
+};
+
+}  // namespace spp

@@ -14,6 +14,7 @@
 // the audit witness) are skipped for the whole wave.  Work is split over S slices of the base range to
 // fill 256 CUs; a second kernel folds the S partial sums per proof through LDS.
 #include "kernels.hpp"
+#include "f29.hpp"
 
 namespace spp {
 
@@ -140,6 +141,25 @@ struct Recoder {
 // ----------------------------------------------------------------------------------------------------
 // MSM accumulate: lane g -> (slice = g / P, proof p = g % P)
 // ----------------------------------------------------------------------------------------------------
+// accumulator used by the table walk: G1 runs on the unsaturated 9x29-bit form (f29.hpp), G2 on XYZZ<Fq2>
+template <class F>
+struct MsmAcc {
+  XYZZ<F> a;
+  __device__ __forceinline__ void init() { a = XYZZ<F>::infinity(); }
+  __device__ __forceinline__ void madd(Affine<F> e, bool sgn) {
+    if (sgn) e.y = e.y.neg();
+    a.madd(e);
+  }
+  __device__ __forceinline__ XYZZ<F> result() const { return a; }
+};
+template <>
+struct MsmAcc<Fq> {
+  XYZZ29<FqParams> a;
+  __device__ __forceinline__ void init() { a = XYZZ29<FqParams>::infinity(); }
+  __device__ __forceinline__ void madd(const Affine<Fq>& e, bool sgn) { a.madd(e, sgn); }
+  __device__ __forceinline__ XYZZ<Fq> result() const { return a.to_xyzz(); }
+};
+
 template <class F>
 __global__ void __launch_bounds__(256) k_msm_fixed(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ rows,
                                                    const Fr* __restrict__ scalars, XYZZ<F>* __restrict__ partial, uint32_t N,
@@ -150,7 +170,8 @@ __global__ void __launch_bounds__(256) k_msm_fixed(const Affine<F>* __restrict__
   const uint32_t E = 1u << (c - 1);
   // slice s takes bases s, s+S, s+2S, ...: neighbouring wires have similar scalar sizes (runs of bits, runs of hash
   // states), so a strided split gives every slice the same mix and the launch no tail of heavy slices
-  XYZZ<F> acc = XYZZ<F>::infinity();
+  MsmAcc<F> acc;
+  acc.init();
   for (uint32_t i = slice; i < N; i += S) {
     Fr s = scalars[(size_t)rows[i] * P + p];
     if (s.is_zero()) continue;
@@ -163,13 +184,11 @@ __global__ void __launch_bounds__(256) k_msm_fixed(const Affine<F>* __restrict__
       bool sgn;
       uint32_t d = rc.next(c, sgn);
       if (d != 0) {
-        Affine<F> e = table[((size_t)(row >> 6) * E + (d - 1)) * 64 + (row & 63)];
-        if (sgn) e.y = e.y.neg();
-        acc.madd(e);
+        acc.madd(table[((size_t)(row >> 6) * E + (d - 1)) * 64 + (row & 63)], sgn);
       }
     }
   }
-  partial[(size_t)slice * P + p] = acc;
+  partial[(size_t)slice * P + p] = acc.result();
 }
 
 // fold S partial sums per proof: one 64-lane block per proof
