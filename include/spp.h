@@ -44,6 +44,10 @@ extern "C" {
 
 #define SPP_CIRCUIT_WITHDRAW 1   /* noir_circuit/src/main.nr */
 #define SPP_CIRCUIT_AUDIT 2      /* audit_circuit (scripts/generate_audit.py:246-465) */
+/* spp_circuit_build only: the withdraw statement padded with ballast multiplications to the dimensions of the
+ * reference's gnark R1CS (noir_circuit/target/shielded_pool_verifier.ccs: 12 452 constraints, domain 2^14), for
+ * like-for-like throughput figures.  The container it writes is an ordinary SPP_CIRCUIT_WITHDRAW circuit. */
+#define SPP_CIRCUIT_WITHDRAW_REFSHAPE 3
 
 #define SPP_PROOF_LEN 388        /* withdraw.rs:13, submit_audit.rs:18 */
 #define SPP_WITHDRAW_PW_LEN 172  /* withdraw.rs:14-16 */

@@ -483,7 +483,7 @@ std::pair<LC, LC> gadget_grumpkin_fixed_base(Builder& b, const std::vector<LC>& 
 // =====================================================================================================
 // Withdraw circuit: noir_circuit/src/main.nr:38-82
 // =====================================================================================================
-Circuit build_withdraw_circuit(bool native_hints) {
+Circuit build_withdraw_circuit(bool native_hints, uint32_t pad_to_constraints) {
   Builder b(CIRCUIT_WITHDRAW);
   // public inputs, in the .pw order (withdraw.rs:74-90)
   LC root = b.public_input();
@@ -537,6 +537,16 @@ Circuit build_withdraw_circuit(bool native_hints) {
   // 6. recipient != 0                                main.nr:80-81
   b.div(LC::constant(Fr::one()), recipient);
 
+  // Optional ballast (SPP_CIRCUIT_WITHDRAW_REFSHAPE): the same statement padded to the size of the reference's gnark
+  // R1CS (12 452 constraints, domain 2^14; its Grumpkin arithmetic runs on an emulated field).  Each step is one
+  // multiplication of full-size values, t <- (t + k) * t, so the added wires cost the MSMs and NTTs what real
+  // constraints cost.  Soundness of the statement is unchanged: the chain constrains only its own wires.
+  if (pad_to_constraints) {
+    Circuit probe = Builder(b).finish();          // lookups/commitment add constraints at finish(): measure them
+    uint32_t have = probe.n_constraints;
+    LC t = randomness;
+    for (uint32_t k = 0; have + k < pad_to_constraints; k++) t = b.mul(t + LC::constant(Fr::from_u64(k + 1)), t);
+  }
   return b.finish();
 }
 

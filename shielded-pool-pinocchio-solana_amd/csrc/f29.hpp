@@ -19,6 +19,12 @@
 #pragma once
 #include "bn254.hpp"
 
+#if defined(__HIPCC__)
+#define SPP_HD_COLD __host__ __device__ __attribute__((noinline))
+#else
+#define SPP_HD_COLD __attribute__((noinline))
+#endif
+
 namespace spp {
 
 template <class Pm>
@@ -175,31 +181,24 @@ struct F29 {
     return r;
   }
 
-  // normalised value == k*p for some 0 <= k <= kmax ?  (normalised form is unique, so this is a limb comparison;
-  // the low limb filters out all but ~kmax/2^29 of the non-zero cases)
-  SPP_HD bool is_zero_mod_p(uint32_t kmax) const {
-    bool hit = false;
-    uint32_t lo = 0;
-    for (uint32_t k = 0; k <= kmax; k++) {
-      hit |= (l[0] == lo);
-      lo = (lo + P9(0)) & M;
+  // normalised value == k*p for some 0 <= k <= KMAX ?  The normalised form is unique, so this is a limb comparison;
+  // the low limbs of 0, p, .., KMAX*p are distinct (p odd), so the low limb both filters (all but ~KMAX/2^29 of the
+  // non-zero cases leave here) and names the only multiple left to compare.
+  template <uint32_t KMAX>
+  SPP_HD bool is_zero_mod_p() const {
+    uint32_t kk = 0xffffffffu;
+    SPP_UNROLL for (uint32_t k = 0; k <= KMAX; k++) {
+      if (l[0] == ((k * P9(0)) & M)) kk = k;
     }
-    if (!hit) return false;
-    uint32_t kp[9];
-    SPP_UNROLL for (int i = 0; i < 9; i++) kp[i] = 0;
-    for (uint32_t k = 0; k <= kmax; k++) {
-      uint32_t diff = 0;
-      SPP_UNROLL for (int i = 0; i < 9; i++) diff |= l[i] ^ kp[i];
-      if (diff == 0) return true;
-      uint32_t carry = 0;
-      SPP_UNROLL for (int i = 0; i < 8; i++) {
-        const uint32_t t = kp[i] + P9(i) + carry;
-        kp[i] = t & M;
-        carry = t >> 29;
-      }
-      kp[8] += P9(8) + carry;
+    if (kk == 0xffffffffu) return false;
+    uint32_t diff = 0, carry = 0;
+    SPP_UNROLL for (int i = 0; i < 8; i++) {
+      const uint32_t t = kk * P9(i) + carry;     // KMAX * 2^29 < 2^32
+      diff |= l[i] ^ (t & M);
+      carry = t >> 29;
     }
-    return false;
+    diff |= l[8] ^ (kk * P9(8) + carry);
+    return diff == 0;
   }
 
   // ---- domain changes ---------------------------------------------------------------------------------
@@ -250,7 +249,6 @@ struct XYZZ29 {
   static SPP_HD XYZZ29 from_xyzz(const XYZZ<B>& q) {
     XYZZ29 r;
     r.inf = q.is_inf();
-    if (r.inf) return infinity();
     r.X = F::from_fp(q.X);
     r.Y = F::from_fp(q.Y);
     // zz*R -> zz*R' -> zz*R'^2/R (K29_IN as a plain factor); rare path (doubling fallback)
@@ -272,31 +270,37 @@ struct XYZZ29 {
       inf = false;
       return;
     }
+    // statement order keeps few values alive at once (x2 dies first, then U2, P, PP, ...)
     const F U2 = x2 * ZZ;                                                // 1 x 1
-    const F S2 = y2 * ZZZ;                                               // 2 x 1
     const F Pp = F::template sub_norm<Pm::SUBC_6P_1>(U2, X);             // normalised, < 7.1 p
-    const F Rr = F::template sub_norm<Pm::SUBC_2P_1>(S2, Y);             // normalised, < 3.1 p
-    if (Pp.is_zero_mod_p(7)) {
-      if (Rr.is_zero_mod_p(3)) {
+    if (Pp.template is_zero_mod_p<7>()) {                                // same x: doubling or cancellation (rare)
+      const F S2 = y2 * ZZZ;
+      const F Rr = F::template sub_norm<Pm::SUBC_2P_1>(S2, Y);
+      if (Rr.template is_zero_mod_p<3>()) {
         XYZZ<B> t = to_xyzz();
         t.dbl_inplace();
-        *this = from_xyzz(t);
+        const XYZZ29 d = from_xyzz(t);
+        X = d.X;
+        Y = d.Y;
+        ZZ = d.ZZ;
+        ZZZ = d.ZZZ;
       } else {
-        *this = infinity();
+        inf = true;
       }
       return;
     }
     const F PP = Pp.sqr();                                               // 1 x 1 -> < 1.3 p
-    const F PPP = Pp * PP;                                               // < 1.06 p
     const F Q = X * PP;                                                  // < 1.05 p
+    const F PPP = Pp * PP;                                               // < 1.06 p
+    ZZ = ZZ * PP;
+    const F S2 = y2 * ZZZ;                                               // 2 x 1
+    const F Rr = F::template sub_norm<Pm::SUBC_2P_1>(S2, Y);             // normalised, < 3.1 p
+    ZZZ = ZZZ * PPP;
     const F R2 = Rr.sqr();                                               // < 1.06 p
-    const F X3 = F::template sub3_norm<Pm::SUBC_4P_3>(R2, PPP, Q);       // normalised, < 5.1 p
-    const F T = F::template sub_lazy<Pm::SUBC_6P_1>(Q, X3);              // limbs < 3, < 7.1 p
+    X = F::template sub3_norm<Pm::SUBC_4P_3>(R2, PPP, Q);                // normalised, < 5.1 p
+    const F T = F::template sub_lazy<Pm::SUBC_6P_1>(Q, X);               // limbs < 3, < 7.1 p
     const F Yn = F::template neg_lazy<Pm::SUBC_2P_1>(Y);                 // limbs < 2, <= 2p
     Y = F::mul2(Rr, T, Yn, PPP);                                         // 1x3 + 2x1 -> < 1.2 p
-    ZZ = ZZ * PP;
-    ZZZ = ZZZ * PPP;
-    X = X3;
   }
 };
 

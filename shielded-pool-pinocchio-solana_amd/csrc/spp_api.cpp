@@ -317,6 +317,8 @@ extern "C" int spp_circuit_build(int circuit_id, const uint32_t* aux, const char
   Circuit c;
   if (circuit_id == SPP_CIRCUIT_WITHDRAW) {
     c = build_withdraw_circuit(true);
+  } else if (circuit_id == SPP_CIRCUIT_WITHDRAW_REFSHAPE) {
+    c = build_withdraw_circuit(true, 12452);
   } else if (circuit_id == SPP_CIRCUIT_AUDIT) {
     if (!aux) return fail(SPP_ERR_BAD_INPUT, "audit circuit needs the RLWE public key (aux)");
     c = build_audit_circuit(aux, aux + 1024, true);

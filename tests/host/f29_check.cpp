@@ -54,9 +54,9 @@ template <class Pm> static void field_tests(const char* name) {
     CHECK(add_norm(a9, b9).to_fp() == a + b, "add_norm");
     CHECK((add_lazy(a9, b9) * c9).to_fp() == (a + b) * c, "add_lazy");
     F z = F::template sub_norm<Pm::SUBC_6P_1>(a9, a9);
-    CHECK(z.is_zero_mod_p(7), "zero");
+    CHECK(z.template is_zero_mod_p<7>(), "zero");
     F nz = F::template sub_norm<Pm::SUBC_6P_1>(a9, b9);
-    CHECK(nz.is_zero_mod_p(7) == (a == b), "nonzero");
+    CHECK(nz.template is_zero_mod_p<7>() == (a == b), "nonzero");
   }
   // extremal limbs: top limb of a value just below 2p is ~6.3M; use words with all-ones low limbs
   const uint32_t top2p = (uint32_t)(((uint64_t)Pm::TWOP(7) << 32 | Pm::TWOP(6)) >> 40) - 1;   // bits 232.. of 2p, minus 1

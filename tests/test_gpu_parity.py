@@ -59,6 +59,32 @@ def test_msm_g1_matches_oracle(ctx):
         assert got == out.raw, (n, wb)
 
 
+def test_msm_g1_repeated_and_cancelling_bases(ctx):
+    """Many copies of one base (and of its negative) with equal scalars: inside a lane the accumulator meets the very
+    point it holds (doubling path of XYZZ29::madd) or its negative (cancellation to infinity and restart)."""
+    from oracle import bn254 as B, native
+    import ctypes
+    rng = random.Random(21)
+    g = B.g1_mul(B.G1_GEN, 0x1234567)
+    neg = (g[0], (B.P - g[1]) % B.P)
+    other = B.g1_mul(B.G1_GEN, 99)
+    for pattern in ("same", "cancel", "mixed"):
+        n = 1500
+        if pattern == "same":
+            pts, sc = [g] * n, [5] * n
+        elif pattern == "cancel":
+            pts, sc = [g if i % 2 == 0 else neg for i in range(n)], [77] * n
+            pts[-1], sc[-1] = other, 3                      # leave something non-trivial
+        else:
+            pts = [rng.choice((g, neg, other)) for _ in range(n)]
+            sc = [rng.choice((1, 2, 255, B.R - 1, rng.randrange(B.R))) for _ in range(n)]
+        bases = b"".join(B.g1_to_bytes(q) for q in pts)
+        got = ctx.msm_g1(bases, sc, 8)
+        out = ctypes.create_string_buffer(64)
+        native.lib().orc_msm_g1(bases, b"".join(s.to_bytes(32, "big") for s in sc), n, ctypes.cast(out, ctypes.c_void_p))
+        assert got == out.raw, pattern
+
+
 def test_setup_matches_oracle(ctx, withdraw_artifacts, workdir):
     pk2 = os.path.join(workdir, "gpu.pk")
     vk2 = os.path.join(workdir, "gpu.vk")
@@ -156,6 +182,32 @@ def test_odd_batch_sizes_and_default_window(ctx, withdraw_artifacts, withdraw_ka
             for i in sorted({0, count // 2, count - 1}):
                 rc, proof, pw = orc.prove(batch[i], rs[i][0], rs[i][1])
                 assert proofs[i] == proof and pws[i] == pw, (count, i)
+    finally:
+        h.close()
+
+
+def test_reference_shape_withdraw_circuit_matches_oracle(ctx, tmp_path, withdraw_kat):
+    """The withdraw statement padded to the reference R1CS's dimensions (12 452 constraints, 2^14): GPU proof bytes ==
+    C oracle under the same pk and (r, s), and the pairing check passes."""
+    import spp
+    from oracle import native, groth16
+    sppc, pk, vk = (str(tmp_path / ("wref." + e)) for e in ("sppc", "pk", "vk"))
+    assert spp.build_circuit(spp.lib.SPP_CIRCUIT_WITHDRAW_REFSHAPE, sppc) == 12452
+    native.setup(sppc, b"\x0b" * 32, pk, vk)
+    os.environ["SPP_TABLE_BUDGET_GB"] = "24"
+    h = ctx.load_circuit(sppc, pk, 0)
+    del os.environ["SPP_TABLE_BUDGET_GB"]
+    try:
+        assert h.n_constraints == 12452 and h.domain_log == 14
+        rows = _withdraw_variants(withdraw_kat, 3)
+        rs = [(101 + i, 202 + i) for i in range(3)]
+        proofs, pws, status = h.prove_batch(rows, rs)
+        assert status == [0, 0, 0]
+        orc = native.Prover(sppc, pk)
+        for i in range(3):
+            rc, proof, pw = orc.prove(rows[i], rs[i][0], rs[i][1])
+            assert rc == 0 and proofs[i] == proof and pws[i] == pw
+        assert groth16.verify(open(vk, "rb").read(), proofs[0], pws[0])
     finally:
         h.close()
 

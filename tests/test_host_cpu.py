@@ -232,3 +232,41 @@ def test_cli_compile_verify_and_toml(tmp_path, withdraw_artifacts, withdraw_kat,
     assert cli.main(["verify", withdraw_artifacts["vk"], str(tmp_path / "a.proof"), str(tmp_path / "a.pw")]) == 0
     (tmp_path / "b.proof").write_bytes(bytes([proof[0] ^ 1]) + proof[1:])
     assert cli.main(["verify", withdraw_artifacts["vk"], str(tmp_path / "b.proof"), str(tmp_path / "a.pw")]) == 1
+
+
+def test_f29_unsaturated_arithmetic_host_check(tmp_path):
+    """csrc/f29.hpp (the 9x29-bit limb form the G1 MSM accumulators run on) against Fp on random and extremal-limb
+    inputs, and XYZZ29::madd chains (doubling / cancellation / negated entries) against XYZZ<Fq>::madd."""
+    exe = str(tmp_path / "f29_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "shielded-pool-pinocchio-solana_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "host", "f29_check.cpp"), "-o", exe], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert out.strip().splitlines()[-1].startswith("OK "), out
+
+
+def test_f29_limb_bounds_certificate():
+    """Interval arithmetic over the generated constants: no 64-bit column can overflow, every lifted subtraction
+    constant dominates its subtrahend, and the accumulator's value bounds are inductive."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("f29_bounds", os.path.join(ROOT, "tests", "host", "f29_bounds.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    for params in ("FqParams", "FrParams"):
+        log = m.check_madd(params)
+        assert log["Y3"] < 1.2 and log["PP"] < 1.3
+
+
+def test_withdraw_reference_shape_circuit(tmp_path, withdraw_kat):
+    """SPP_CIRCUIT_WITHDRAW_REFSHAPE: same statement, ballast up to the reference's gnark R1CS size (12 452 constraints,
+    domain 2^14: SURVEY F6); the Python interpreter accepts the golden inputs and still refuses a wrong root."""
+    import spp
+    from oracle import circuit as C
+    path = str(tmp_path / "wref.sppc")
+    assert spp.build_circuit(spp.lib.SPP_CIRCUIT_WITHDRAW_REFSHAPE, path) == 12452
+    c = C.Circuit(path)
+    assert c.id == 1 and c.domain_log == 14 and (c.n_public - 1, c.n_secret) == (5, 21) and c.n_wires > 12000
+    good = C.withdraw_inputs(withdraw_kat)
+    chal = lambda w: 0xabcdef
+    assert C.first_unsatisfied(c, C.solve(c, good, chal)) == -1
+    bad = list(good); bad[0] += 1
+    assert C.first_unsatisfied(c, C.solve(c, bad, chal)) >= 0
