@@ -304,4 +304,158 @@ struct XYZZ29 {
   }
 };
 
+// --------------------------------------------------------------------------------------------------------------
+// Fq2 = Fq[u]/(u^2+1) over F29 and the G2 accumulator.  Every component is a sum of products reduced once:
+//   mul : c0 = a0*b0 + (C - a1)*b1,  c1 = a0*b1 + a1*b0            (4 products, 2 reductions)
+//   sqr : c0 = (a0 + a1)*(a0 - a1 + C),  c1 = (2*a0)*a1            (2 products, 2 reductions)
+// Operands are normalised (limbs < 2^29); the negations/sums made on the fly have limbs < 2^30 or 3*2^29, which keeps
+// the column sums under 2^64 (sum of limb-bound products <= 6 * 2^58 per column term: tests/host/f29_bounds.py).
+// CNEG_x = lifted multiple of p that dominates the component being negated (template parameter per call site).
+// --------------------------------------------------------------------------------------------------------------
+struct F29x2 {
+  using F = F29<FqParams>;
+  using Pm = FqParams;
+  F c0, c1;
+
+  static SPP_HD F29x2 from_words(const Fq2& a) { return {F::from_words(a.c0.l), F::from_words(a.c1.l)}; }
+  // (a0 + a1 u)(b0 + b1 u); CA dominates a1
+  template <F::ConstFn CA>
+  static SPP_HD F29x2 mul(const F29x2& a, const F29x2& b) {
+    const F na1 = F::template neg_lazy<CA>(a.c1);
+    return {F::mul2(a.c0, b.c0, na1, b.c1), F::mul2(a.c0, b.c1, a.c1, b.c0)};
+  }
+  // by a real constant (components scale independently)
+  SPP_HD F29x2 mul_real(const F& k) const { return {c0 * k, c1 * k}; }
+  // CA dominates a1
+  template <F::ConstFn CA>
+  SPP_HD F29x2 sqr() const {
+    const F s = add_lazy(c0, c1);
+    const F d = F::template sub_lazy<CA>(c0, c1);
+    const F t = add_lazy(c0, c0);
+    return {s * d, t * c1};
+  }
+  template <F::ConstFn C>
+  static SPP_HD F29x2 sub_norm(const F29x2& a, const F29x2& b) {
+    return {F::template sub_norm<C>(a.c0, b.c0), F::template sub_norm<C>(a.c1, b.c1)};
+  }
+  template <F::ConstFn C>
+  static SPP_HD F29x2 sub3_norm(const F29x2& a, const F29x2& b, const F29x2& c2) {
+    return {F::template sub3_norm<C>(a.c0, b.c0, c2.c0), F::template sub3_norm<C>(a.c1, b.c1, c2.c1)};
+  }
+  template <F::ConstFn C>
+  static SPP_HD F29x2 neg_lazy(const F29x2& a) {
+    return {F::template neg_lazy<C>(a.c0), F::template neg_lazy<C>(a.c1)};
+  }
+  template <uint32_t KMAX>
+  SPP_HD bool is_zero_mod_p() const {
+    return c0.template is_zero_mod_p<KMAX>() && c1.template is_zero_mod_p<KMAX>();
+  }
+  SPP_HD Fq2 to_fp() const { return {c0.to_fp(), c1.to_fp()}; }
+  SPP_HD Fq2 scaled_to_fp() const { return {c0.scaled_to_fp(), c1.scaled_to_fp()}; }
+  static SPP_HD F29x2 from_fp(const Fq2& a) { return {F::from_fp(a.c0), F::from_fp(a.c1)}; }
+};
+
+// G2 accumulator: same formulas and domains as XYZZ29 (X, Y in the R' domain, ZZ/ZZZ scaled by R'^2/R).
+// Value bounds per component: X < 5.6 p, Y < 1.5 p, ZZ/ZZZ < 1.3 p (certificate: check_madd_g2).
+struct XYZZ29G2 {
+  using E = F29x2;
+  using F = F29<FqParams>;
+  using Pm = FqParams;
+  E X, Y, ZZ, ZZZ;
+  bool inf;
+
+  static SPP_HD XYZZ29G2 infinity() {
+    XYZZ29G2 r;
+    SPP_UNROLL for (int i = 0; i < 9; i++) {
+      r.X.c0.l[i] = r.X.c1.l[i] = r.Y.c0.l[i] = r.Y.c1.l[i] = 0;
+      r.ZZ.c0.l[i] = r.ZZ.c1.l[i] = r.ZZZ.c0.l[i] = r.ZZZ.c1.l[i] = 0;
+    }
+    r.inf = true;
+    return r;
+  }
+  SPP_HD XYZZ<Fq2> to_xyzz() const {
+    if (inf) return XYZZ<Fq2>::infinity();
+    return {X.to_fp(), Y.to_fp(), ZZ.scaled_to_fp(), ZZZ.scaled_to_fp()};
+  }
+  static SPP_HD XYZZ29G2 from_xyzz(const XYZZ<Fq2>& q) {
+    XYZZ29G2 r;
+    r.inf = q.is_inf();
+    const F k = F::template konst<Pm::K29_IN>();
+    r.X = E::from_fp(q.X);
+    r.Y = E::from_fp(q.Y);
+    r.ZZ = E::from_fp(q.ZZ).mul_real(k);
+    r.ZZZ = E::from_fp(q.ZZZ).mul_real(k);
+    return r;
+  }
+
+  // this += (x2, +-y2); e = table entry (Fq2 words, not infinity)
+  SPP_HD void madd(const Affine<Fq2>& e, bool negate) {
+    const E x2 = E::from_words(e.x);                                     // limbs < 1, value < 2p
+    const E y2 = E::from_words(e.y);
+    if (inf) {
+      const F k = F::template konst<Pm::K29_IN>();
+      X = x2.mul_real(k);
+      const E yn = E::template neg_lazy<Pm::SUBC_4P_1>(y2);               // limbs < 2, <= 4p
+      E ys;
+      SPP_UNROLL for (int i = 0; i < 9; i++) {
+        ys.c0.l[i] = negate ? yn.c0.l[i] : y2.c0.l[i];
+        ys.c1.l[i] = negate ? yn.c1.l[i] : y2.c1.l[i];
+      }
+      Y = ys.mul_real(k);                                                // < 1.03 p
+      SPP_UNROLL for (int i = 0; i < 9; i++) {
+        ZZ.c0.l[i] = k.l[i];
+        ZZ.c1.l[i] = 0;
+      }
+      ZZZ = ZZ;
+      inf = false;
+      return;
+    }
+    const E U2 = E::template mul<Pm::SUBC_4P_1>(x2, ZZ);                 // < 1.1 p
+    const E Pp = E::template sub_norm<Pm::SUBC_6P_1>(U2, X);             // normalised, < 7.1 p
+    E S2 = E::template mul<Pm::SUBC_4P_1>(y2, ZZZ);                      // < 1.1 p
+    if (negate) S2 = E::template neg_lazy<Pm::SUBC_2P_1>(S2);            // limbs < 2, <= 2p
+    const E Rr = E::template sub_norm<Pm::SUBC_2P_1>(S2, Y);             // normalised, < 4.1 p
+    if (Pp.template is_zero_mod_p<7>()) {                                // same x: doubling or cancellation (rare)
+      if (Rr.template is_zero_mod_p<4>()) {
+        XYZZ<Fq2> t = to_xyzz();
+        t.dbl_inplace();
+        const XYZZ29G2 d = from_xyzz(t);
+        X = d.X;
+        Y = d.Y;
+        ZZ = d.ZZ;
+        ZZZ = d.ZZZ;
+      } else {
+        inf = true;
+      }
+      return;
+    }
+    const E PP = Pp.template sqr<Pm::SUBC_8P_1>();                       // < 2.3 p
+    const E Q = E::template mul<Pm::SUBC_6P_1>(X, PP);                   // < 1.2 p
+    const E PPP = E::template mul<Pm::SUBC_8P_1>(Pp, PP);                // < 1.3 p
+    ZZ = E::template mul<Pm::SUBC_2P_1>(ZZ, PP);
+    ZZZ = E::template mul<Pm::SUBC_2P_1>(ZZZ, PPP);
+    const E R2 = Rr.template sqr<Pm::SUBC_6P_1>();                       // < 1.6 p
+    X = E::template sub3_norm<Pm::SUBC_4P_3>(R2, PPP, Q);                // normalised, < 5.6 p
+    const E T = E::template sub_norm<Pm::SUBC_6P_1>(Q, X);               // normalised, < 7.2 p
+    // Y3 = R*T - Y*PPP: eight products, two reductions
+    const F nR1 = F::template neg_lazy<Pm::SUBC_6P_1>(Rr.c1);
+    const F nY0 = F::template neg_lazy<Pm::SUBC_2P_1>(Y.c0);
+    const F nY1 = F::template neg_lazy<Pm::SUBC_2P_1>(Y.c1);
+    uint64_t c[18];
+    F::clear(c);
+    F::mac(c, Rr.c0, T.c0);
+    F::mac(c, nR1, T.c1);
+    F::mac(c, nY0, PPP.c0);
+    F::mac(c, Y.c1, PPP.c1);
+    const F y0 = F::reduce(c);
+    F::clear(c);
+    F::mac(c, Rr.c0, T.c1);
+    F::mac(c, Rr.c1, T.c0);
+    F::mac(c, nY0, PPP.c1);
+    F::mac(c, nY1, PPP.c0);
+    Y.c0 = y0;
+    Y.c1 = F::reduce(c);
+  }
+};
+
 }  // namespace spp

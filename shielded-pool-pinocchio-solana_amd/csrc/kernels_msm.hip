@@ -141,7 +141,8 @@ struct Recoder {
 // ----------------------------------------------------------------------------------------------------
 // MSM accumulate: lane g -> (slice = g / P, proof p = g % P)
 // ----------------------------------------------------------------------------------------------------
-// accumulator used by the table walk: G1 runs on the unsaturated 9x29-bit form (f29.hpp), G2 on XYZZ<Fq2>
+// accumulator used by the table walk: G1 and G2 run on the unsaturated 9x29-bit form (f29.hpp); the generic
+// template (saturated Fp words) is kept for other coordinate fields
 template <class F>
 struct MsmAcc {
   XYZZ<F> a;
@@ -158,6 +159,14 @@ struct MsmAcc<Fq> {
   __device__ __forceinline__ void init() { a = XYZZ29<FqParams>::infinity(); }
   __device__ __forceinline__ void madd(const Affine<Fq>& e, bool sgn) { a.madd(e, sgn); }
   __device__ __forceinline__ XYZZ<Fq> result() const { return a.to_xyzz(); }
+};
+
+template <>
+struct MsmAcc<Fq2> {
+  XYZZ29G2 a;
+  __device__ __forceinline__ void init() { a = XYZZ29G2::infinity(); }
+  __device__ __forceinline__ void madd(const Affine<Fq2>& e, bool sgn) { a.madd(e, sgn); }
+  __device__ __forceinline__ XYZZ<Fq2> result() const { return a.to_xyzz(); }
 };
 
 template <class F>

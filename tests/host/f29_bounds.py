@@ -142,6 +142,66 @@ def check_madd(struct="FqParams"):
     return dict(cx.log)
 
 
+def check_madd_g2():
+    """XYZZ29G2::madd (Fq2 components), same line order as f29.hpp."""
+    cx = Ctx("FqParams")
+    p = cx.p
+    norm = V.normalised
+
+    def add_lazy(a, b):
+        return V([a.l[i] + b.l[i] for i in range(9)], a.v + b.v)
+
+    def mul(a, b, ca, what):          # F29x2::mul<CA>
+        na1 = cx.neg_lazy(a[1], ca, what + " -a1")
+        return (cx.mul2(a[0], b[0], na1, b[1], what + ".c0"), cx.mul2(a[0], b[1], a[1], b[0], what + ".c1"))
+
+    def sqr(a, ca, what):             # F29x2::sqr<CA>
+        s = add_lazy(a[0], a[1])
+        d = cx.sub_lazy(a[0], a[1], ca, what + " a0-a1")
+        t = add_lazy(a[0], a[0])
+        return (cx.mul(s, d, what + ".c0"), cx.mul(t, a[1], what + ".c1"))
+
+    def sub_norm(a, b, c, what):
+        return tuple(cx.sub_norm(a[i], b[i], c, what) for i in range(2))
+
+    X = (norm(int(5.6 * p)),) * 2
+    Y = (norm(int(1.5 * p)),) * 2
+    ZZ = (norm(int(1.3 * p)),) * 2
+    ZZZ = (norm(int(1.3 * p)),) * 2
+    x2 = (norm(2 * p),) * 2
+    y2 = (norm(2 * p),) * 2
+    kin = norm(p)
+    # first addition
+    yn = cx.neg_lazy(y2[0], "SUBC_4P_1", "y2 negated")
+    assert cx.mul(x2[0], kin, "X0").v <= X[0].v and cx.mul(yn, kin, "Y0").v <= Y[0].v
+    U2 = mul(x2, ZZ, "SUBC_4P_1", "U2")
+    Pp = sub_norm(U2, X, "SUBC_6P_1", "P")
+    S2 = mul(y2, ZZZ, "SUBC_4P_1", "S2")
+    S2n = tuple(cx.neg_lazy(c, "SUBC_2P_1", "-S2") for c in S2)          # the larger of the two forms
+    Rr = sub_norm(S2n, Y, "SUBC_2P_1", "R")
+    assert Pp[0].v <= 8 * p and Rr[0].v <= 5 * p                          # is_zero_mod_p<7> / <4>
+    PP = sqr(Pp, "SUBC_8P_1", "PP")
+    Q = mul(X, PP, "SUBC_6P_1", "Q")
+    PPP = mul(Pp, PP, "SUBC_8P_1", "PPP")
+    ZZ3 = mul(ZZ, PP, "SUBC_2P_1", "ZZ3")
+    ZZZ3 = mul(ZZZ, PPP, "SUBC_2P_1", "ZZZ3")
+    R2 = sqr(Rr, "SUBC_6P_1", "R2")
+    X3 = tuple(cx.sub3_norm(R2[i], PPP[i], Q[i], "SUBC_4P_3", "X3") for i in range(2))
+    T = sub_norm(Q, X3, "SUBC_6P_1", "T")
+    nR1 = cx.neg_lazy(Rr[1], "SUBC_6P_1", "-R1")
+    nY0 = cx.neg_lazy(Y[0], "SUBC_2P_1", "-Y0")
+    nY1 = cx.neg_lazy(Y[1], "SUBC_2P_1", "-Y1")
+    Y3 = (cx.columns([(Rr[0], T[0]), (nR1, T[1]), (nY0, PPP[0]), (Y[1], PPP[1])], "Y3.c0"),
+          cx.columns([(Rr[0], T[1]), (Rr[1], T[0]), (nY0, PPP[1]), (nY1, PPP[0])], "Y3.c1"))
+    for nm, new, old in (("X", X3, X), ("Y", Y3, Y), ("ZZ", ZZ3, ZZ), ("ZZZ", ZZZ3, ZZZ)):
+        for i in range(2):
+            assert new[i].v <= old[i].v, (nm, i, new[i].v / p)
+    for nm, v in (("X", X[0]), ("Y", Y[0]), ("ZZ", ZZ[0])):
+        assert cx.mul(v, norm(p), nm + " out").v < 2 * p
+    return dict(cx.log)
+
+
 if __name__ == "__main__":
+    print("G2", {k: round(v, 3) for k, v in check_madd_g2().items()})
     for s in ("FqParams", "FrParams"):
         print(s, {k: round(v, 3) for k, v in check_madd(s).items()})

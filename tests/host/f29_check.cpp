@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
+#include <cstring>
 #include <vector>
 #include "f29.hpp"
 using namespace spp;
@@ -109,7 +110,68 @@ static void curve_tests() {
   printf("curve ok\n");
 }
 
+static Fq fq_hex(const char* h) {
+  uint32_t c[8];
+  for (int i = 0; i < 8; i++) {
+    char buf[9];
+    memcpy(buf, h + 8 * i, 8);
+    buf[8] = 0;
+    c[7 - i] = (uint32_t)strtoul(buf, nullptr, 16);
+  }
+  return Fq::from_canonical(c);
+}
+
+static void fq2_tests() {
+  using E = F29x2;
+  for (int it = 0; it < 1000; it++) {
+    Fq2 a{rnd_field<Fq>(), rnd_field<Fq>()}, b{rnd_field<Fq>(), rnd_field<Fq>()};
+    E a9 = E::from_fp(a), b9 = E::from_fp(b);
+    CHECK(E::mul<FqParams::SUBC_2P_1>(a9, b9).to_fp() == a * b, "fq2 mul");
+    CHECK(a9.sqr<FqParams::SUBC_2P_1>().to_fp() == a.sqr(), "fq2 sqr");
+  }
+  printf("fq2 field ok\n");
+}
+
+static void g2_tests() {
+  // BN254 G2 generator (EIP-197), x = x0 + x1 u, y = y0 + y1 u
+  G2Affine G{{fq_hex("1800deef121f1e76426a00665e5c4479674322d4f75edadd46debd5cd992f6ed"),
+              fq_hex("198e9393920d483a7260bfb731fb5d25f1aa493335a9e71297e485b7aef312c2")},
+             {fq_hex("12c85ea5db8c6deb4aab71808dcb408fe3d1e7690c43d37b4ce6cc0166fa7daa"),
+              fq_hex("090689d0585ff075ec9e99ad690c3395bc4b313370b38ef355acdadcd122975b")}};
+  std::vector<G2Affine> pts;
+  for (int i = 0; i < 12; i++) {
+    uint32_t k[8];
+    for (int j = 0; j < 8; j++) k[j] = rnd32();
+    k[7] &= 0x0fffffff;
+    pts.push_back(scalar_mul(G, k).to_affine());
+  }
+  for (int trial = 0; trial < 20; trial++) {
+    G2XYZZ ref = G2XYZZ::infinity();
+    XYZZ29G2 acc = XYZZ29G2::infinity();
+    for (int s = 0; s < 40; s++) {
+      int idx = rnd32() % pts.size();
+      bool neg = rnd32() & 1;
+      int mode = rnd32() % 16;
+      G2Affine e = pts[idx];
+      if (mode == 0 && !ref.is_inf()) { e = ref.to_affine(); neg = false; }
+      if (mode == 1 && !ref.is_inf()) { e = ref.to_affine(); neg = true; }
+      G2Affine en = e;
+      if (neg) en.y = en.y.neg();
+      ref.madd(en);
+      acc.madd(e, neg);
+      CHECK(acc.inf == ref.is_inf(), "g2 inf flag");
+      if (!ref.is_inf()) {
+        G2Affine a = ref.to_affine(), b = acc.to_xyzz().to_affine();
+        CHECK(a.x == b.x && a.y == b.y, "g2 madd chain");
+      }
+    }
+  }
+  printf("g2 ok\n");
+}
+
 int main() {
+  fq2_tests();
+  g2_tests();
   field_tests<FqParams>("fq");
   field_tests<FrParams>("fr");
   curve_tests();

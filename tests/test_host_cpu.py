@@ -254,6 +254,8 @@ def test_f29_limb_bounds_certificate():
     for params in ("FqParams", "FrParams"):
         log = m.check_madd(params)
         assert log["Y3"] < 1.2 and log["PP"] < 1.3
+    g2 = m.check_madd_g2()
+    assert g2["Y3.c0"] < 1.5 and g2["PP.c0"] < 2.3
 
 
 def test_withdraw_reference_shape_circuit(tmp_path, withdraw_kat):
