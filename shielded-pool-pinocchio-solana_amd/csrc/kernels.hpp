@@ -17,6 +17,8 @@ struct DevSparse {
   const uint32_t* rowptr;
   const uint32_t* wire;
   const uint32_t* coeff;   // bit31: coefficient is +1, bit30: coefficient is -1, low bits: table index
+  const uint32_t* lit;     // 0, or the coefficient itself when |c| < 2^28: magnitude, bit31 = negative (matrix evaluation
+                           // accumulates those terms as wide integers instead of doing a field multiplication each)
 };
 static constexpr uint32_t COEFF_ONE = 0x80000000u;
 static constexpr uint32_t COEFF_MINUS_ONE = 0x40000000u;

@@ -385,6 +385,52 @@ void launch_count8(hipStream_t st, DevCircuit dc, Fr* W, uint32_t* counters, uin
 // ---------------------------------------------------------------------------------------------------
 // constraint evaluation + satisfaction check: lane -> (constraint k, proof p)
 // ---------------------------------------------------------------------------------------------------
+// Row dot product for the matrix evaluation.  Terms whose coefficient is a small integer (the audit circuit's 1 088
+// quotient rows carry 1 024 public-key coefficients < 2^28 each, generate_audit.py:57-66,236-243) are summed as plain
+// integers, c * (w*R) into a 320-bit accumulator (8 multiply-adds per term instead of a ~300-instruction Montgomery
+// product), positives and negatives apart; the two sums are reduced once per row: the element whose Montgomery word is
+// X = X_lo + 2^256 * X_hi is elem(X_lo mod p) + X_hi.
+__device__ __forceinline__ void wide_mac(uint32_t (&acc)[10], uint32_t c, const Fr& x) {
+  uint32_t carry = 0;
+  SPP_UNROLL for (int i = 0; i < 8; i++) {
+    const uint64_t t = (uint64_t)c * x.l[i] + acc[i] + carry;
+    acc[i] = (uint32_t)t;
+    carry = (uint32_t)(t >> 32);
+  }
+  const uint64_t t = (uint64_t)acc[8] + carry;
+  acc[8] = (uint32_t)t;
+  acc[9] += (uint32_t)(t >> 32);
+}
+__device__ __forceinline__ Fr wide_finish(const uint32_t (&acc)[10]) {
+  Fr lo;
+  SPP_UNROLL for (int i = 0; i < 8; i++) lo.l[i] = acc[i];
+  Fr::cond_sub_2p(lo.l);   // < 2^256 < 6p  ->  < 4p  ->  < 2p
+  Fr::cond_sub_2p(lo.l);
+  if ((acc[8] | acc[9]) == 0) return lo;
+  return lo + Fr::from_u64((uint64_t)acc[8] | ((uint64_t)acc[9] << 32));
+}
+__device__ __forceinline__ Fr dev_row_dot_wide(const DevSparse& m, const Fr* __restrict__ coeffs, uint32_t k, const Fr* __restrict__ W,
+                                                uint32_t P, uint32_t p) {
+  Fr acc = Fr::zero();
+  uint32_t pos[10], neg[10];
+  SPP_UNROLL for (int i = 0; i < 10; i++) pos[i] = neg[i] = 0;
+  bool any = false;
+  const uint32_t b = m.rowptr[k], e = m.rowptr[k + 1];
+  for (uint32_t t = b; t < e; t++) {
+    const uint32_t ci = m.coeff[t], li = m.lit[t];
+    const Fr w = W[(size_t)m.wire[t] * P + p];
+    if (ci & COEFF_ONE) acc = acc + w;
+    else if (ci & COEFF_MINUS_ONE) acc = acc - w;
+    else if (li) {
+      any = true;
+      if (li & 0x80000000u) wide_mac(neg, li & 0x7fffffffu, w);
+      else wide_mac(pos, li, w);
+    } else acc = acc + coeffs[ci & COEFF_MASK] * w;
+  }
+  if (any) acc = acc + wide_finish(pos) - wide_finish(neg);
+  return acc;
+}
+
 __global__ void __launch_bounds__(256) k_spmv_check(DevCircuit dc, const Fr* __restrict__ W, Fr* __restrict__ abc, uint32_t n, uint32_t P,
                                                     uint32_t* __restrict__ status) {
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -393,9 +439,9 @@ __global__ void __launch_bounds__(256) k_spmv_check(DevCircuit dc, const Fr* __r
   const uint32_t p = (uint32_t)(g % P), k = (uint32_t)(g / P);
   Fr a = Fr::zero(), b = Fr::zero(), c = Fr::zero();
   if (k < dc.n_constraints) {
-    a = dev_row_dot(dc.A, dc.coeffs, k, 0, W, P, p);
-    b = dev_row_dot(dc.B, dc.coeffs, k, 0, W, P, p);
-    c = dev_row_dot(dc.C, dc.coeffs, k, 0, W, P, p);
+    a = dev_row_dot_wide(dc.A, dc.coeffs, k, W, P, p);
+    b = dev_row_dot_wide(dc.B, dc.coeffs, k, W, P, p);
+    c = dev_row_dot_wide(dc.C, dc.coeffs, k, W, P, p);
     if (a * b != c) atomicOr(&status[p], 1u);
   }
   abc[g] = a;

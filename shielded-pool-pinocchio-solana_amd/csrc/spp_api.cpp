@@ -213,17 +213,33 @@ static int own_upload(spp_circuit* c, T** dst, const std::vector<T>& src) {
   return 0;
 }
 static int upload_sparse(spp_circuit* c, const Circuit& circ, const Sparse& m, DevSparse* out) {
-  std::vector<uint32_t> wire(m.terms.size()), coeff(m.terms.size());
+  std::vector<uint32_t> wire(m.terms.size()), coeff(m.terms.size()), lit(m.terms.size(), 0);
   Fr one = Fr::one(), mone = Fr::one().neg();
+  // small literals, per coefficient-table entry: canonical value v < 2^28, or p - v < 2^28
+  std::vector<uint32_t> small(circ.coeffs.size(), 0);
+  for (size_t ci = 0; ci < circ.coeffs.size(); ci++) {
+    uint32_t v[8], nv[8];
+    circ.coeffs[ci].to_canonical(v);
+    bool hi0 = true;
+    for (int k = 1; k < 8; k++) hi0 = hi0 && v[k] == 0;
+    if (hi0 && v[0] != 0 && v[0] < (1u << 28)) { small[ci] = v[0]; continue; }
+    circ.coeffs[ci].neg().to_canonical(nv);
+    hi0 = true;
+    for (int k = 1; k < 8; k++) hi0 = hi0 && nv[k] == 0;
+    if (hi0 && nv[0] != 0 && nv[0] < (1u << 28)) small[ci] = nv[0] | 0x80000000u;
+  }
   for (size_t i = 0; i < m.terms.size(); i++) {
     wire[i] = m.terms[i].wire;
     uint32_t ci = m.terms[i].coeff;
     uint32_t flag = 0;
     if (circ.coeffs[ci] == one) flag = COEFF_ONE;
     else if (circ.coeffs[ci] == mone) flag = COEFF_MINUS_ONE;
+    else lit[i] = small[ci];
     coeff[i] = ci | flag;
   }
-  uint32_t *rp, *w, *co;
+  uint32_t *rp, *w, *co, *li;
+  if (int e = own_upload(c, &li, lit)) return e;
+  out->lit = li;
   if (int e = own_upload(c, &rp, m.rowptr)) return e;
   if (int e = own_upload(c, &w, wire)) return e;
   if (int e = own_upload(c, &co, coeff)) return e;
@@ -675,8 +691,12 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
 
   for (int k = 0; k < 2; k++) {
     Workspace& w = c->ws[k];
-    w.st = ctx->pstream[k];
-    HIP_TRY(hipStreamCreate(&w.st2));
+    // SPP_SERIAL=1 (profiling aid): one stream for everything, so per-stage / per-kernel times are not stretched by
+    // the other batch or by the G2 side stream
+    const bool serial = getenv("SPP_SERIAL") != nullptr;
+    w.st = ctx->pstream[serial ? 0 : k];
+    if (serial) w.st2 = w.st;
+    else HIP_TRY(hipStreamCreate(&w.st2));
     HIP_TRY(hipEventCreateWithFlags(&w.ev_w, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&w.ev_b2, hipEventDisableTiming));
     for (auto& evt : w.ev) HIP_TRY(hipEventCreate(&evt));
@@ -702,7 +722,7 @@ static void destroy_circuit(spp_circuit* c) {
   hipStreamSynchronize(c->ctx->stream);
   for (auto& w : c->ws) {
     if (w.st) hipStreamSynchronize(w.st);
-    if (w.st2) { hipStreamSynchronize(w.st2); hipStreamDestroy(w.st2); }
+    if (w.st2 && w.st2 != w.st) { hipStreamSynchronize(w.st2); hipStreamDestroy(w.st2); }
     if (w.ev_w) hipEventDestroy(w.ev_w);
     if (w.ev_b2) hipEventDestroy(w.ev_b2);
     free_workspace(w);
