@@ -75,7 +75,7 @@ def _dot(m, k, w):
 
 
 def _poseidon_native(state, out, w):
-    """Writes x^2, x^4, x^5 of every S-box in gadget order; returns next free wire."""
+    """Writes x^2, x^3, x^4, x^5 of every S-box in gadget order; returns next free wire."""
     t = len(state)
     rf, rp, rc, mds = hashes.poseidon_params(t)
     s = list(state)
@@ -85,10 +85,11 @@ def _poseidon_native(state, out, w):
         for i in (range(t) if full else (0,)):
             x = s[i]
             x2 = x * x % R
-            x4 = x2 * x2 % R
+            x3 = x2 * x % R
+            x4 = x3 * x % R
             x5 = x4 * x % R
-            w[out], w[out + 1], w[out + 2] = x2, x4, x5
-            out += 3
+            w[out], w[out + 1], w[out + 2], w[out + 3] = x2, x3, x4, x5
+            out += 4
             s[i] = x5
         s = [sum(mds[i][j] * s[j] for j in range(t)) % R for i in range(t)]
     return out
@@ -101,7 +102,7 @@ def _poseidon2_native(state, out, w):
 
     def sbox(x):
         nonlocal out
-        x2 = x * x % R
+        x2 = x * x % R            # Poseidon2 keeps the three-wire S-box (x^2, x^4, x^5)
         x4 = x2 * x2 % R
         x5 = x4 * x % R
         w[out], w[out + 1], w[out + 2] = x2, x4, x5

@@ -484,23 +484,23 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
   if (pk.circuit_id != circ.id || pk.n_wires != circ.n_wires || pk.domain_log != circ.domain_log)
     return fail(SPP_ERR_FORMAT, "proving key does not match the circuit");
   // window bits per MSM set: uniform when requested, otherwise a greedy split of the HBM budget (env
-  // SPP_TABLE_BUDGET_GB, default 200, capped at 75 % of the free HBM): repeatedly widen the set whose next window bit
+  // SPP_TABLE_BUDGET_GB, default 240 of the 288 GB, capped at 85 % of the free HBM): repeatedly widen the set whose next window bit
   // removes the most mixed-addition work per extra byte (one bit ~ -8 % additions, x2 table; a G2 addition is
-  // weighted 2.7 G1 additions).  The two commitment sets only ever see bytes / small counters: fixed 9-bit windows.
+  // weighted 3 G1 additions, as measured).  The two commitment sets only ever see bytes / small counters: fixed 9-bit windows.
   uint32_t cw[7];   // A, B1, K, Z, CB, CS, B2
   {
     const double nset[7] = {(double)pk.A.size() + 2, (double)pk.B1.size() + 2, (double)pk.K.size() + 1, (double)pk.Z.size(),
                             (double)pk.CB.size(), (double)pk.CS.size(), (double)pk.B2.size() + 2};
-    const double esz[7] = {64, 64, 64, 64, 64, 64, 128}, wgt[7] = {1, 1, 1, 1, 0, 0, 2.7};
+    const double esz[7] = {64, 64, 64, 64, 64, 64, 128}, wgt[7] = {1, 1, 1, 1, 0, 0, 3.0};
     auto bytes = [&](int s, int cb) { return nset[s] * esz[s] * msm_windows((uint32_t)cb) * (double)(1u << (cb - 1)); };
     if (window_bits != 0) {
       for (int s = 0; s < 7; s++) cw[s] = (uint32_t)window_bits;
     } else {
       size_t free_b = 0, total_b = 0;
       HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-      double budget = 200e9;
+      double budget = 240e9;
       if (const char* env = getenv("SPP_TABLE_BUDGET_GB")) budget = atof(env) * 1e9;
-      budget = std::min(budget, 0.75 * (double)free_b);
+      budget = std::min(budget, 0.85 * (double)free_b);
       int cur[7] = {6, 6, 6, 6, 9, 9, 6};
       double used = 0;
       for (int s = 0; s < 7; s++) used += bytes(s, cur[s]);
