@@ -141,6 +141,11 @@ struct Recoder {
 // ----------------------------------------------------------------------------------------------------
 // MSM accumulate: lane g -> (slice = g / P, proof p = g % P)
 // ----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool words_all_zero(const Fq& v) {
+  uint32_t o = 0;
+  SPP_UNROLL for (int i = 0; i < 8; i++) o |= v.l[i];
+  return o == 0;
+}
 // accumulator used by the table walk: G1 and G2 run on the unsaturated 9x29-bit form (f29.hpp); the generic
 // template (saturated Fp words) is kept for other coordinate fields
 template <class F>
@@ -157,7 +162,10 @@ template <>
 struct MsmAcc<Fq> {
   XYZZ29<FqParams> a;
   __device__ __forceinline__ void init() { a = XYZZ29<FqParams>::infinity(); }
-  __device__ __forceinline__ void madd(const Affine<Fq>& e, bool sgn) { a.madd(e, sgn); }
+  __device__ __forceinline__ void madd(const Affine<Fq>& e, bool sgn) {
+    if (words_all_zero(e.x) && words_all_zero(e.y)) return;   // table row of an infinity base (spp_msm_g1 callers)
+    a.madd(e, sgn);
+  }
   __device__ __forceinline__ XYZZ<Fq> result() const { return a.to_xyzz(); }
 };
 
@@ -165,7 +173,10 @@ template <>
 struct MsmAcc<Fq2> {
   XYZZ29G2 a;
   __device__ __forceinline__ void init() { a = XYZZ29G2::infinity(); }
-  __device__ __forceinline__ void madd(const Affine<Fq2>& e, bool sgn) { a.madd(e, sgn); }
+  __device__ __forceinline__ void madd(const Affine<Fq2>& e, bool sgn) {
+    if (words_all_zero(e.x.c0) && words_all_zero(e.x.c1) && words_all_zero(e.y.c0) && words_all_zero(e.y.c1)) return;
+    a.madd(e, sgn);
+  }
   __device__ __forceinline__ XYZZ<Fq2> result() const { return a.to_xyzz(); }
 };
 

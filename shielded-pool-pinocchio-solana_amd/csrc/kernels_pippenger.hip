@@ -12,6 +12,7 @@
 // HBM traffic is dominated by step 4: every base is gathered once per window (64 B x N x 16), on top of the
 // algorithmic 96 B x N; bucket sizes are N / 2^15 +- sqrt for uniform scalars, so one lane per bucket balances.
 #include "kernels.hpp"
+#include "f29.hpp"
 
 namespace spp {
 
@@ -89,14 +90,14 @@ __global__ void __launch_bounds__(256) k_pip_buckets(const G1Affine* __restrict_
   const uint32_t j = g / PIP_B;
   const uint32_t* seg = sorted + (size_t)j * n + offs[g];
   const uint32_t cnt = hist[g];
-  G1XYZZ acc = G1XYZZ::infinity();
+  XYZZ29<FqParams> acc = XYZZ29<FqParams>::infinity();   // unsaturated 9x29-bit accumulator (f29.hpp), as in k_msm_fixed
   for (uint32_t k = 0; k < cnt; k++) {
     const uint32_t e = seg[k];
-    G1Affine p = bases[e & 0x7fffffffu];
-    if (e & 0x80000000u) p.y = p.y.neg();
-    acc.madd(p);
+    const G1Affine p = bases[e & 0x7fffffffu];
+    if (p.is_inf()) continue;
+    acc.madd(p, (e & 0x80000000u) != 0);
   }
-  buckets[g] = acc;
+  buckets[g] = acc.to_xyzz();
 }
 
 // chunk c of window j: S = sum_b B_b, T = sum_b (b_local + 1) B_b  (running-sum trick from the top bucket down)

@@ -83,6 +83,17 @@ def test_msm_g1_repeated_and_cancelling_bases(ctx):
         out = ctypes.create_string_buffer(64)
         native.lib().orc_msm_g1(bases, b"".join(s.to_bytes(32, "big") for s in sc), n, ctypes.cast(out, ctypes.c_void_p))
         assert got == out.raw, pattern
+        if pattern == "mixed":
+            # bases at infinity (64 zero bytes) contribute nothing, whatever their scalars
+            holes = list(range(0, n, 7))
+            with_inf = bytearray(bases)
+            sc2 = list(sc)
+            for i in holes:
+                with_inf[64 * i:64 * i + 64] = bytes(64)
+            kept = [i for i in range(n) if i not in set(holes)]
+            native.lib().orc_msm_g1(b"".join(bases[64 * i:64 * i + 64] for i in kept), b"".join(sc2[i].to_bytes(32, "big") for i in kept),
+                                    len(kept), ctypes.cast(out, ctypes.c_void_p))
+            assert ctx.msm_g1(bytes(with_inf), sc2, 8) == out.raw
 
 
 def test_setup_matches_oracle(ctx, withdraw_artifacts, workdir):
