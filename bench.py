@@ -242,7 +242,8 @@ def main():
         return out
 
     default_batch = {"withdraw": 2048, "audit": 512, "withdraw_refshape": 1024}
-    main_res = run_circuit(args.circuit, args.batch or default_batch[args.circuit], args.steps, args.warmup, not args.no_cpu_baseline)
+    main_res = run_circuit(args.circuit, args.batch or default_batch[args.circuit], args.steps, args.warmup,
+                           not args.no_cpu_baseline and world == 1)   # CPU baseline: rank 0 at N=1 only
     # the other circuit of BASELINE.json's metric, as a secondary figure (single GPU runs only)
     other = None
     if world == 1 and not args.no_secondary:
