@@ -84,7 +84,7 @@ void spp_free_ctx(spp_ctx* ctx);
 int spp_setup(spp_ctx* ctx, const char* circuit_path, const uint8_t seed[32], const char* pk_path, const char* vk_path);
 
 /* Loads R1CS + proving key, builds the window tables in HBM. window_bits in [4,16] = the same window for every MSM set;
- * 0 = per-set windows chosen greedily within env SPP_TABLE_BUDGET_GB (default 200) and 75 % of the free HBM. */
+ * 0 = per-set windows chosen greedily within env SPP_TABLE_BUDGET_GB (default 240) and 85 % of the free HBM; env SPP_SERIAL=1 (profiling aid) puts both batch workspaces and the G2 MSM on one stream. */
 int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const char* pk_path, int window_bits, spp_circuit** out);
 void spp_free_circuit(spp_circuit* c);
 /* info[0..7] = id, n_public (without the constant), n_secret, n_wires, n_constraints, domain_log, n_inputs, window_bits */

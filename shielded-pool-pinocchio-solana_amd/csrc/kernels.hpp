@@ -30,6 +30,10 @@ struct DevCircuit {
   const Fr* aux;            // hint constants (Grumpkin window tables)
   const uint32_t* program;
   uint32_t n_wires, n_constraints, n_public, n_inputs, challenge_wire;
+  // matrix evaluation: constraints grouped into runs of consecutive rows whose B rows are identical (the four
+  // constraints of a Poseidon S-box share B = the S-box input): run r covers rows run_start[r] .. run_start[r+1]-1
+  const uint32_t* run_start;
+  uint32_t n_runs;
   // hash constants (Montgomery)
   const Fr* pos3_rc;  const Fr* pos3_mds;   // t=3: 195 rc, 9 mds (row-major)
   const Fr* pos5_rc;  const Fr* pos5_mds;   // t=5: 340 rc, 25 mds

@@ -445,26 +445,39 @@ __device__ __forceinline__ Fr dev_row_dot_wide(const DevSparse& m, const Fr* __r
   return acc;
 }
 
+// lane -> (run r of constraints with one shared B row, proof p); lanes past the last run zero-fill the padding rows
+// n_constraints .. n-1 of the evaluation domain
 __global__ void __launch_bounds__(256) k_spmv_check(DevCircuit dc, const Fr* __restrict__ W, Fr* __restrict__ abc, uint32_t n, uint32_t P,
                                                     uint32_t* __restrict__ status) {
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t lanes = (uint64_t)(dc.n_runs + (n - dc.n_constraints)) * P;
+  if (g >= lanes) return;
+  const uint32_t p = (uint32_t)(g % P), r = (uint32_t)(g / P);
   const uint64_t total = (uint64_t)n * P;
-  if (g >= total) return;
-  const uint32_t p = (uint32_t)(g % P), k = (uint32_t)(g / P);
-  Fr a = Fr::zero(), b = Fr::zero(), c = Fr::zero();
-  if (k < dc.n_constraints) {
-    a = dev_row_dot_wide(dc.A, dc.coeffs, k, W, P, p);
-    b = dev_row_dot_wide(dc.B, dc.coeffs, k, W, P, p);
-    c = dev_row_dot_wide(dc.C, dc.coeffs, k, W, P, p);
-    if (a * b != c) atomicOr(&status[p], 1u);
+  if (r >= dc.n_runs) {
+    const uint64_t o = (uint64_t)(dc.n_constraints + (r - dc.n_runs)) * P + p;
+    abc[o] = Fr::zero();
+    abc[total + o] = Fr::zero();
+    abc[2 * total + o] = Fr::zero();
+    return;
   }
-  abc[g] = a;
-  abc[total + g] = b;
-  abc[2 * total + g] = c;
+  const uint32_t k0 = dc.run_start[r], k1 = dc.run_start[r + 1];
+  const Fr b = dev_row_dot_wide(dc.B, dc.coeffs, k0, W, P, p);
+  bool bad = false;
+  for (uint32_t k = k0; k < k1; k++) {
+    const Fr a = dev_row_dot_wide(dc.A, dc.coeffs, k, W, P, p);
+    const Fr c = dev_row_dot_wide(dc.C, dc.coeffs, k, W, P, p);
+    bad |= (a * b != c);
+    const uint64_t o = (uint64_t)k * P + p;
+    abc[o] = a;
+    abc[total + o] = b;
+    abc[2 * total + o] = c;
+  }
+  if (bad) atomicOr(&status[p], 1u);
 }
 void launch_spmv_check(hipStream_t st, DevCircuit dc, const Fr* W, Fr* abc, uint32_t n, uint32_t P, uint32_t* status) {
-  uint64_t total = (uint64_t)n * P;
-  hipLaunchKernelGGL(k_spmv_check, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, dc, W, abc, n, P, status);
+  const uint64_t lanes = (uint64_t)(dc.n_runs + (n - dc.n_constraints)) * P;
+  hipLaunchKernelGGL(k_spmv_check, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, st, dc, W, abc, n, P, status);
 }
 
 }  // namespace spp

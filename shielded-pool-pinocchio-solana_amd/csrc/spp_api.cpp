@@ -545,6 +545,28 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
   c->dc.program = d_prog;
   c->dc.n_wires = circ.n_wires;
   c->dc.n_constraints = circ.n_constraints;
+  {
+    // runs of consecutive constraints with identical B rows (at most 8 long, so lanes stay comparable in cost)
+    std::vector<uint32_t> runs;
+    auto same_b = [&](uint32_t k) {
+      const uint32_t a0 = circ.B.rowptr[k - 1], a1 = circ.B.rowptr[k], b1 = circ.B.rowptr[k + 1];
+      if (a1 - a0 != b1 - a1 || a1 == a0) return false;
+      for (uint32_t t = 0; t < a1 - a0; t++)
+        if (circ.B.terms[a0 + t].wire != circ.B.terms[a1 + t].wire || circ.B.terms[a0 + t].coeff != circ.B.terms[a1 + t].coeff) return false;
+      return true;
+    };
+    uint32_t len = 0;
+    for (uint32_t k = 0; k < circ.n_constraints; k++) {
+      if (k == 0 || len >= 8 || !same_b(k)) { runs.push_back(k); len = 0; }
+      len++;
+    }
+    const uint32_t n_runs = (uint32_t)runs.size();
+    runs.push_back(circ.n_constraints);
+    uint32_t* d_runs;
+    if ((e = own_upload(c, &d_runs, runs))) return e;
+    c->dc.run_start = d_runs;
+    c->dc.n_runs = n_runs;
+  }
   c->dc.n_public = circ.n_public;
   c->dc.n_inputs = circ.n_inputs();
   c->dc.challenge_wire = circ.challenge_wire;
