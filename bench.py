@@ -197,6 +197,30 @@ def main():
                 assert h.L.spp_prove_batch(*args_h) == 0
             host_rate = 3 * B / (time.perf_counter() - th)
 
+        # SURVEY 8d Config 2: ONE withdraw proof from the reference's own inputs (client/prover-params.toml, committed as
+        # tests/golden/withdraw_kat.json), end to end on the device-resident entry point: latency, and proofs/s at batch 1
+        single = None
+        if rank == 0 and circuit == "withdraw":
+            from oracle import circuit as OC
+            kat_row = OC.withdraw_inputs(json.load(open(os.path.join(ROOT, "tests", "golden", "withdraw_kat.json"))))
+            one_in = torch.frombuffer(bytearray(b"".join(int(v).to_bytes(32, "big") for v in kat_row)), dtype=torch.uint8).to(dev)
+            one_rs = torch.frombuffer(bytearray((5).to_bytes(32, "big") + (6).to_bytes(32, "big")), dtype=torch.uint8).to(dev)
+            one_pr = torch.zeros(388, dtype=torch.uint8, device=dev)
+            one_pw = torch.zeros(h.pw_len, dtype=torch.uint8, device=dev)
+            one_st = torch.zeros(1, dtype=torch.int32, device=dev)
+            lat = []
+            for _ in range(12):
+                torch.cuda.synchronize()
+                tl = time.perf_counter()
+                h.prove_batch_device(1, one_in.data_ptr(), one_rs.data_ptr(), one_pr.data_ptr(), one_pw.data_ptr(), one_st.data_ptr())
+                h.sync()
+                lat.append((time.perf_counter() - tl) * 1e3)
+            assert int(one_st.item()) == 0
+            assert spp.verify(open(vkp, "rb").read(), one_pr.cpu().numpy().tobytes(), one_pw.cpu().numpy().tobytes())
+            lat = sorted(lat[2:])
+            single = {"inputs": "client/prover-params.toml (tests/golden/withdraw_kat.json)", "latency_ms_median": round(lat[len(lat) // 2], 3),
+                      "latency_ms_min": round(lat[0], 3), "proofs_per_s_at_batch_1": round(1e3 / lat[len(lat) // 2], 2)}
+
         out = None
         if rank == 0:
             # the timed batches produced real proofs: check two of the last step with the product's own pairing verifier
@@ -239,6 +263,8 @@ def main():
                              "avg_launch_ms": round(avg_ms, 4), "launches_timed": acc["kern_n"],
                              "note": "integer-VALU bound (about 2.3K instructions, 1.5K of them v_mad_u64_u32, per mixed addition); HBM fraction reported as mandated"},
             }
+            if single is not None:
+                out["single_proof"] = single
             if want_cpu:
                 orc = native.Prover(sppc, pkp)
                 cores = native.max_threads()
@@ -251,7 +277,12 @@ def main():
                     assert rc == 0
                     done += cores
                 dt = time.perf_counter() - t1
+                t2 = time.perf_counter()
+                for i in range(3):
+                    assert orc.prove(rows[i % len(rows)], 3 + i, 4 + i)[0] == 0
+                one_ms = (time.perf_counter() - t2) / 3 * 1e3
                 out["cpu_baseline"] = {"value": round(done / dt, 3), "unit": "proofs/s", "cores": cores, "kind": "port",
+                                       "single_proof_latency_ms": round(one_ms, 1),
                                        "sample": "%d %s proofs, one per host thread, oracle C/OpenMP prover (stands in for the Sunspot "
                                                  "Go/CPU path, which cannot run here: no Go toolchain, no pk)" % (done, circuit)}
         h.close()
@@ -276,7 +307,7 @@ def main():
         line = {"metric": "Groth16 proofs/sec", "value": main_res["value"], "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "u32x8 (254-bit Montgomery integers)", "data": "synthetic"}
-        for k in ("config", "stage_ms_per_step", "roofline", "cpu_baseline"):
+        for k in ("config", "stage_ms_per_step", "roofline", "cpu_baseline", "single_proof"):
             if k in main_res:
                 line[k] = main_res[k]
         if other is not None:

@@ -187,6 +187,10 @@ int spp_msm_g1_pippenger(spp_ctx* ctx, const uint8_t* bases, const uint8_t* scal
  * an LCG of `seed`; scale_be (optional) multiplies every scalar (linearity checks). Mean ms over `iters` runs. */
 int spp_msm_g1_pippenger_bench(spp_ctx* ctx, size_t n, uint64_t seed, const uint8_t scale_be[32], int iters, uint8_t out[64],
                                float* ms_total, float* ms_bucket_kernel);
+/* Same with a "witness-like" scalar distribution: small_permille / 1000 of the scalars are byte-sized (SURVEY 8d Config 5:
+ * 70 % of a gnark witness is small), the rest uniform. */
+int spp_msm_g1_pippenger_bench_dist(spp_ctx* ctx, size_t n, uint64_t seed, uint32_t small_permille, const uint8_t scale_be[32], int iters,
+                                    uint8_t out[64], float* ms_total, float* ms_bucket_kernel);
 
 #ifdef __cplusplus
 }

@@ -1551,7 +1551,11 @@ extern "C" int spp_msm_g1_pippenger(spp_ctx* ctx, const uint8_t* bases, const ui
 // scale: if nonzero, every scalar is multiplied by it first (linearity checks: MSM(scale * s) = scale * MSM(s)).
 extern "C" int spp_msm_g1_pippenger_bench(spp_ctx* ctx, size_t n, uint64_t seed, const uint8_t scale_be[32], int iters, uint8_t out[64],
                                           float* ms_total, float* ms_bucket_kernel) {
-  if (!ctx || !out || n == 0 || iters <= 0) return fail(SPP_ERR_BAD_INPUT, "bad argument");
+  return spp_msm_g1_pippenger_bench_dist(ctx, n, seed, 0, scale_be, iters, out, ms_total, ms_bucket_kernel);
+}
+extern "C" int spp_msm_g1_pippenger_bench_dist(spp_ctx* ctx, size_t n, uint64_t seed, uint32_t small_permille, const uint8_t scale_be[32],
+                                               int iters, uint8_t out[64], float* ms_total, float* ms_bucket_kernel) {
+  if (!ctx || !out || n == 0 || iters <= 0 || small_permille > 1000) return fail(SPP_ERR_BAD_INPUT, "bad argument");
   if (n > (1u << 26)) return fail(SPP_ERR_BAD_INPUT, "n too large");
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_TRY(hipSetDevice(ctx->device));
@@ -1569,6 +1573,8 @@ extern "C" int spp_msm_g1_pippenger_bench(spp_ctx* ctx, size_t n, uint64_t seed,
     w[7] &= 0x1fffffffu;   // < 2^253 < r
     Fr s;
     for (int k = 0; k < 8; k++) s.l[k] = w[k];
+    // witness-like: a byte-sized VALUE (Config 5); the uniform ones are raw words of a random element anyway
+    if (small_permille && (next() >> 20) % 1000 < small_permille) s = Fr::from_u64(w[0] & 0xffu);
     sc[i] = scale_be ? s * scale : s;   // both are fixed representations of the same field element family
   }
   DevBuf dk, ds, dp, dw, dt, dg, dtmp, dpre;

@@ -63,12 +63,13 @@ class Context:
         check(self.L.spp_msm_g1_pippenger(self.h, bases_bytes, sc, len(scalars), ctypes.cast(out, ctypes.c_void_p)))
         return out.raw
 
-    def msm_g1_pippenger_bench(self, n, seed=5, scale=None, iters=1):
-        """Returns (result bytes, ms per MSM, ms of the bucket kernel)."""
+    def msm_g1_pippenger_bench(self, n, seed=5, scale=None, iters=1, small_permille=0):
+        """Returns (result bytes, ms per MSM, ms of the bucket kernel). small_permille: share of byte-sized scalars."""
         out = ctypes.create_string_buffer(64)
         t, k = ctypes.c_float(0), ctypes.c_float(0)
         sb = None if scale is None else int(scale).to_bytes(32, "big")
-        check(self.L.spp_msm_g1_pippenger_bench(self.h, n, seed, sb, iters, ctypes.cast(out, ctypes.c_void_p), ctypes.byref(t), ctypes.byref(k)))
+        check(self.L.spp_msm_g1_pippenger_bench_dist(self.h, n, seed, int(small_permille), sb, iters, ctypes.cast(out, ctypes.c_void_p),
+                                                     ctypes.byref(t), ctypes.byref(k)))
         return out.raw, t.value, k.value
 
 

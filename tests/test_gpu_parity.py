@@ -399,6 +399,58 @@ def test_pippenger_matches_oracle_and_is_linear(ctx):
     assert r3 == out.raw
 
 
+def test_pippenger_skewed_scalars(ctx):
+    """Witness-like distributions (SURVEY 8d Config 5): most scalars byte-sized, so a few buckets of window 0 hold
+    thousands of points and span many 256-entry segments of the sorted list (k_pip_segments / k_pip_fixup)."""
+    from oracle import bn254 as B, native
+    import ctypes
+    rng = random.Random(33)
+    pts = []
+    p = B.G1_GEN
+    for i in range(200):
+        p = B.g1_add(p, B.g1_mul(B.G1_GEN, rng.randrange(1, 1 << 64)))
+        pts.append(p)
+    n = 5000
+    idx = [rng.randrange(200) for _ in range(n)]
+    bases = b"".join(B.g1_to_bytes(pts[i]) for i in idx)
+    sc = [7] * 2300 + [B.R - 7] * 300 + [rng.randrange(256) for _ in range(1500)] + [rng.randrange(B.R) for _ in range(900)]
+    rng.shuffle(sc)
+    out = ctypes.create_string_buffer(64)
+    native.lib().orc_msm_g1(bases, b"".join(s.to_bytes(32, "big") for s in sc), n, ctypes.cast(out, ctypes.c_void_p))
+    assert ctx.msm_g1_pippenger(bases, sc) == out.raw
+    # exactly one bucket, exactly filling segments: 512 copies of the same digit
+    sc2 = [3] * 512
+    native.lib().orc_msm_g1(bases[:64 * 512], b"".join(s.to_bytes(32, "big") for s in sc2), 512, ctypes.cast(out, ctypes.c_void_p))
+    assert ctx.msm_g1_pippenger(bases[:64 * 512], sc2) == out.raw
+    # the synthetic generator with 70 % byte-sized scalars: oracle on 2^12, linearity on 2^18
+    r3, _, _ = ctx.msm_g1_pippenger_bench(1 << 12, seed=9, small_permille=700)
+    x = (9 * 6364136223846793005 + 1442695040888963407) % (1 << 64)
+    def nxt():
+        nonlocal x
+        x = (x * 6364136223846793005 + 1442695040888963407) % (1 << 64)
+        return x
+    rinv = pow(1 << 256, -1, B.R)
+    ks, ss = [], []
+    for _ in range(1 << 12):
+        ks.append(nxt() | 1)
+        w = []
+        for _ in range(4):
+            v = nxt(); w += [v & 0xffffffff, v >> 32]
+        w[7] &= 0x1fffffff
+        if (nxt() >> 20) % 1000 < 700:
+            ss.append(w[0] & 0xff)
+        else:
+            ss.append(sum(l << (32 * i) for i, l in enumerate(w)) * rinv % B.R)
+    assert sum(1 for v in ss if v < 256) > 2500
+    basesb = b"".join(B.g1_to_bytes(B.g1_mul(B.G1_GEN, kk)) for kk in ks)
+    native.lib().orc_msm_g1(basesb, b"".join(s.to_bytes(32, "big") for s in ss), 1 << 12, ctypes.cast(out, ctypes.c_void_p))
+    assert r3 == out.raw
+    r1, _, _ = ctx.msm_g1_pippenger_bench(1 << 18, seed=5, small_permille=700)
+    k = 0x7654321
+    r2, _, _ = ctx.msm_g1_pippenger_bench(1 << 18, seed=5, scale=k, small_permille=700)
+    assert B.g1_to_bytes(B.g1_mul(B.g1_from_bytes(r1), k)) == r2
+
+
 def test_cli_setup_prove_verify_on_gpu(tmp_path, withdraw_kat):
     """The prove_linux.sh pipeline (compile -> setup -> prove -> verify) through the spp CLI."""
     from spp import cli
