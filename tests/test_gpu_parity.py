@@ -154,6 +154,48 @@ def test_withdraw_proof_bytes_match_oracle_and_verify(withdraw_handle, withdraw_
     assert not groth16.verify(vk, bytes(bad), pws[0])
 
 
+def test_full_size_batch_is_consistent_with_small_batches(withdraw_handle, withdraw_artifacts, withdraw_kat):
+    """BASELINE-size batch (2048 proofs per launch sequence) through a size-independent property: lanes that carry the
+    same inputs and blinding produce the same bytes wherever they sit in the batch, those bytes are the oracle's, and
+    one unsatisfiable row in the middle is refused without disturbing its neighbours."""
+    from oracle import native
+    rows4 = _withdraw_variants(withdraw_kat, 4)
+    rs4 = [(31 + i, 57 + 2 * i) for i in range(4)]
+    B_ = 2048
+    rows = [rows4[i % 4] for i in range(B_)]
+    rs = [rs4[i % 4] for i in range(B_)]
+    bad_at = 1027
+    rows[bad_at] = [rows[bad_at][0] + 1] + rows[bad_at][1:]
+    proofs, pws, status = withdraw_handle.prove_batch(rows, rs)
+    assert status[bad_at] != 0 and proofs[bad_at] == bytes(388)
+    assert all(st == 0 for i, st in enumerate(status) if i != bad_at)
+    for i in range(B_):
+        if i != bad_at:
+            assert proofs[i] == proofs[i % 4] and pws[i] == pws[i % 4], i
+    orc = native.Prover(withdraw_artifacts["sppc"], withdraw_artifacts["pk"])
+    for i in range(4):
+        rc, proof, pw = orc.prove(rows4[i], rs4[i][0], rs4[i][1])
+        assert rc == 0 and proofs[i] == proof and pws[i] == pw
+
+
+def test_load_errors_are_reported(ctx, tmp_path, withdraw_artifacts, audit_artifacts):
+    """Error behaviour at the boundary (negative codes + message, mapped to thrown errors by the addon)."""
+    import spp
+    from spp.lib import SppError
+    with pytest.raises(SppError) as e:
+        ctx.load_circuit(str(tmp_path / "missing.sppc"), withdraw_artifacts["pk"], 6)
+    assert "-3" in str(e.value) or "cannot read" in str(e.value)                    # SPP_ERR_IO
+    with pytest.raises(SppError) as e:
+        ctx.load_circuit(withdraw_artifacts["sppc"], audit_artifacts["pk"], 6)      # key of another circuit
+    assert "does not match" in str(e.value) or "-7" in str(e.value)                 # SPP_ERR_FORMAT
+    bad = tmp_path / "trunc.pk"
+    bad.write_bytes(open(withdraw_artifacts["pk"], "rb").read()[:1000])
+    with pytest.raises(SppError):
+        ctx.load_circuit(withdraw_artifacts["sppc"], str(bad), 6)
+    with pytest.raises(SppError):
+        ctx.load_circuit(withdraw_artifacts["sppc"], withdraw_artifacts["pk"], 3)   # window outside [4,16]
+
+
 def test_withdraw_witness_matches_oracle(withdraw_handle, withdraw_artifacts, withdraw_kat):
     from oracle import native, circuit as C
     row = C.withdraw_inputs(withdraw_kat)
