@@ -110,6 +110,39 @@ def main():
                       "cpu_baseline": {"value": round(1.0 / cpu_s, 2), "unit": "instances/s", "cores": 1, "kind": "port",
                                        "sample": "8 instances, oracle C schoolbook (the reference's CPython path measured 1.4 instances/s/core, BASELINE.md)"}}),
           flush=True)
+    # ---- batched Groth16 verification (`sunspot verify` for many proofs against one key) ----
+    import tempfile
+    from oracle import circuit as OC, groth16
+    tmp = tempfile.mkdtemp(prefix="spp_vb_")
+    sppc, pkp, vkp = (os.path.join(tmp, "w." + e) for e in ("sppc", "pk", "vk"))
+    spp.build_circuit(1, sppc)
+    native.setup(sppc, b"\x07" * 32, pkp, vkp)
+    orc = native.Prover(sppc, pkp)
+    row = OC.withdraw_inputs(json.load(open(os.path.join(ROOT, "tests", "golden", "withdraw_kat.json"))))
+    made = [orc.prove(row, 11 + i, 29 + i) for i in range(4)]
+    assert all(m[0] == 0 for m in made)
+    vk = open(vkp, "rb").read()
+    nver = 1 << 15
+    proofs = [made[i % 4][1] for i in range(nver)]
+    pws = [made[i % 4][2] for i in range(nver)]
+    bad_at = {5, 4097, nver - 1}
+    for i in bad_at:
+        b = bytearray(proofs[i]); b[150] ^= 1; proofs[i] = bytes(b)
+    ctx.verify_batch(vk, proofs[:64], pws[:64])                       # warm-up
+    res, kms = ctx.verify_batch(vk, proofs, pws, want_ms=True)
+    assert all(res[i] == (i not in bad_at) for i in range(nver))
+    t0 = time.perf_counter()
+    assert spp.verify(vk, made[0][1], made[0][2])
+    host_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    assert groth16.verify(vk, made[0][1], made[0][2])
+    py_s = time.perf_counter() - t0
+    print(json.dumps({"metric": "Groth16 verifications/sec (batched, one key)", "value": round(nver / (kms * 1e-3), 1), "unit": "proofs/s",
+                      "config": {"workload": "2^15 withdraw proofs (388 B + 172 B each) against one verifying key: curve and subgroup checks, "
+                                             "commitment proof of knowledge, challenge hash, public-input MSM, 4-pairing product"},
+                      "kernel_ms": round(kms, 3), "host_single_proof_verifier_ms": round(host_ms, 2),
+                      "cpu_baseline": {"value": round(1.0 / py_s, 3), "unit": "proofs/s", "cores": 1, "kind": "port",
+                                       "sample": "1 proof, oracle Python verifier"}}), flush=True)
     ctx.close()
 
 

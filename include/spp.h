@@ -15,6 +15,7 @@
  *   spp_grumpkin_keygen_batch client/merkle.ts:98-113 generateIdentityKeypair
  *   spp_audit_inputs_batch    scripts/generate_audit.py:468-641 (everything before `nargo execute`)
  *   spp_verify                `sunspot verify` noir_circuit/prove_linux.sh:86-87, audit_circuit/prove_audit.sh:98-99
+ *   spp_verify_batch          the same for many proofs on the GPU
  *   spp_shamir_reconstruct / spp_rlwe_decrypt_batch   scripts/rlwe_decrypt.py:61-132, demo-frontend/app/lib/shamir.ts:97-169
  *   spp_msm_g1(_pippenger) / spp_ntt_fr   micro-benchmark entry points (BASELINE.json configs[4]); no reference equivalent
  *
@@ -164,6 +165,13 @@ int spp_audit_inputs_batch(spp_ctx* ctx, const uint32_t* pk_a, const uint32_t* p
                            const int8_t* e1, const int8_t* e2, uint8_t* rows);
 int spp_audit_inputs_batch_device(spp_ctx* ctx, const void* d_pk_a, const void* d_pk_b, size_t count, const void* d_sk, const void* d_r,
                                   const void* d_e1, const void* d_e2, void* d_rows);
+
+/* Batched verification on the GPU (`sunspot verify` for many proofs against one key, the checks of the
+ * deployed verifier withdraw.rs:63-90 / submit_audit.rs:41-54): proofs = count * 388 B, pws = count * pw_len B (host
+ * buffers), ok[i] = 1 iff proof i verifies.  Same decisions as spp_verify; one lane per proof. kernel_ms (optional):
+ * duration of the verification kernel. */
+int spp_verify_batch(spp_ctx* ctx, const uint8_t* vk, size_t vk_len, size_t count, const uint8_t* proofs, const uint8_t* pws, size_t pw_len,
+                     int32_t* ok, float* kernel_ms);
 
 /* ---- auditor side (scripts/rlwe_decrypt.py:61-132, demo-frontend/app/lib/shamir.ts:97-169) ---- */
 /* Shamir reconstruction at 0 over BN254 Fr for n coefficients from t shares: xs[t] share indices, ys = t * n * 32 B

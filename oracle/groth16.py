@@ -68,6 +68,17 @@ def public_witness_bytes(values):
         int(v % B.R).to_bytes(32, "big") for v in values)
 
 
+def _g2_times_r(pt):
+    """[r]pt without reducing the scalar (B.g2_mul reduces mod r)."""
+    acc, add, k = None, pt, B.R
+    while k:
+        if k & 1:
+            acc = B.g2_add(acc, add)
+        add = B.g2_add(add, add)
+        k >>= 1
+    return acc
+
+
 def verify(vk_bytes, proof_bytes, pw_bytes):
     vk = parse_vk(vk_bytes)
     try:
@@ -81,6 +92,8 @@ def verify(vk_bytes, proof_bytes, pw_bytes):
         if not B.g1_is_on_curve(p):
             return False
     if not B.g2_is_on_curve(pr["Bs"]):
+        return False
+    if _g2_times_r(pr["Bs"]) is not None:      # order-r subgroup (the twist has a large cofactor)
         return False
     # Pedersen proof of knowledge of the commitment
     if not B.pairing_product_is_one([(pr["commitment"], vk["ped_G"]), (pr["pok"], vk["ped_GSigmaNeg"])]):

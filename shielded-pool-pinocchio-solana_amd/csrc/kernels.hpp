@@ -77,6 +77,10 @@ void launch_solve(hipStream_t st, DevCircuit dc, Fr* W, Fr* scratch, uint32_t pc
 void launch_batch_div(hipStream_t st, DevCircuit dc, Fr* W, Fr* scratch, uint32_t k0, uint32_t n, uint32_t P);
 void launch_count8(hipStream_t st, DevCircuit dc, Fr* W, uint32_t* counters, uint32_t h0, uint32_t n, uint32_t out0, uint32_t P);
 // a,b,c evaluation + satisfaction check (status[p] |= 1 when some row fails)
+// ---- batched verification (kernels_verify.hip); the structures live in pairing_fast.hpp ----
+struct VerifyKeyDev;
+void launch_verify(hipStream_t st, const VerifyKeyDev* vk, const uint8_t* proofs, const uint8_t* pws, uint32_t pw_len, uint32_t count,
+                   int32_t* ok);
 void launch_spmv_check(hipStream_t st, DevCircuit dc, const Fr* W, Fr* abc, uint32_t n, uint32_t P, uint32_t* status);
 
 // ---- NTT / QAP ----

@@ -130,4 +130,37 @@ SPP_HD Fr fr_from_wide48(const uint32_t w[12]) {
   return l + hm;
 }
 
+// fr.Hash(commitment, "bsb22-commitment"): expand_message_xmd(SHA-256) of the 64 commitment bytes (16 big-endian
+// words, x then y), 48 output bytes -> Fr.  Blocks are laid out by hand (message 64 B, DST 16 B).
+SPP_HD Fr bsb22_challenge(const uint32_t m[16]) {
+  uint32_t blk[16];
+  // b0 = H(Z_pad || msg || I2OSP(48,2) || 0 || DST || len(DST))
+  Sha256 s0;
+  s0.init();
+  for (int i = 0; i < 16; i++) blk[i] = 0;
+  s0.compress(blk);
+  s0.compress(m);
+  blk[0] = 0x00300062u; blk[1] = 0x73623232u; blk[2] = 0x2d636f6du; blk[3] = 0x6d69746du; blk[4] = 0x656e7410u; blk[5] = 0x80000000u;
+  for (int i = 6; i < 15; i++) blk[i] = 0;
+  blk[15] = 0x4a0u;
+  s0.compress(blk);
+  // b1 = H(b0 || 1 || DST')
+  Sha256 s1;
+  s1.init();
+  for (int i = 0; i < 8; i++) blk[i] = s0.h[i];
+  blk[8] = 0x01627362u; blk[9] = 0x32322d63u; blk[10] = 0x6f6d6d69u; blk[11] = 0x746d656eu; blk[12] = 0x74108000u;
+  blk[13] = 0; blk[14] = 0; blk[15] = 0x190u;
+  s1.compress(blk);
+  // b2 = H((b0 ^ b1) || 2 || DST')
+  Sha256 s2;
+  s2.init();
+  for (int i = 0; i < 8; i++) blk[i] = s0.h[i] ^ s1.h[i];
+  blk[8] = 0x02627362u;
+  s2.compress(blk);
+  uint32_t wide[12];
+  for (int i = 0; i < 8; i++) wide[i] = s1.h[i];
+  for (int i = 0; i < 4; i++) wide[8 + i] = s2.h[i];
+  return fr_from_wide48(wide);
+}
+
 }  // namespace spp

@@ -18,6 +18,7 @@
 #include "kernels.hpp"
 #include "sha256.hpp"
 #include "pairing.hpp"
+#include "pairing_fast_host.hpp"
 
 using namespace spp;
 
@@ -1646,6 +1647,7 @@ extern "C" int spp_verify(const uint8_t* vk, size_t vk_len, const uint8_t* proof
   G1Affine Ar = g1_from_raw(proof), Krs = g1_from_raw(proof + 192), Cm = g1_from_raw(proof + 260), Pok = g1_from_raw(proof + 324);
   G2Affine Bs = g2_from_raw(proof + 64);
   if (!g1_on_curve(Ar) || !g1_on_curve(Krs) || !g1_on_curve(Cm) || !g1_on_curve(Pok) || !g2_on_curve(Bs)) return SPP_OK;   // ok = 0
+  if (!g2_in_subgroup(Bs)) return SPP_OK;   // the twist has a large cofactor: Bs must lie in the order-r subgroup
   // Pedersen proof of knowledge of the commitment
   if (!pairing_product_is_one({{Cm, pedG}, {Pok, pedGS}})) return SPP_OK;
   // challenge = hash_to_field(commitment, "bsb22-commitment")
@@ -1664,6 +1666,72 @@ extern "C" int spp_verify(const uint8_t* vk, size_t vk_len, const uint8_t* proof
   }
   ksum.madd(Cm);
   if (pairing_product_is_one({{Ar, Bs}, {alpha1.neg(), beta2}, {ksum.to_affine().neg(), gamma2}, {Krs.neg(), delta2}})) *ok = 1;
+  return SPP_OK;
+}
+
+// -----------------------------------------------------------------------------------------------------
+// batched verification on the GPU: same decisions as spp_verify above, one lane per proof
+// -----------------------------------------------------------------------------------------------------
+extern "C" int spp_verify_batch(spp_ctx* ctx, const uint8_t* vk, size_t vk_len, size_t count, const uint8_t* proofs, const uint8_t* pws,
+                                size_t pw_len, int32_t* ok, float* kernel_ms) {
+  if (!ctx || !vk || !ok || (count && (!proofs || !pws))) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  if (kernel_ms) *kernel_ms = 0;
+  if (count == 0) return SPP_OK;
+  if (count > (1u << 24)) return fail(SPP_ERR_BAD_INPUT, "count too large");
+  auto be32 = [](const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; };
+  if (vk_len < 576 + 4) return fail(SPP_ERR_FORMAT, "verifying key too short");
+  const uint32_t nk = be32(vk + 576);
+  size_t off = 580;
+  if (nk < 2 || vk_len != off + (size_t)nk * 64 + 12 + 256) return fail(SPP_ERR_FORMAT, "verifying key has the wrong length");
+  if (pw_len != 12 + 32 * (size_t)(nk - 2)) return fail(SPP_ERR_FORMAT, "public witness length does not match the verifying key");
+  const G1Affine alpha1 = g1_from_raw(vk);
+  const G2Affine beta2 = g2_from_raw(vk + 128), gamma2 = g2_from_raw(vk + 256), delta2 = g2_from_raw(vk + 448);
+  std::vector<G1Affine> K(nk);
+  for (uint32_t i = 0; i < nk; i++) K[i] = g1_from_raw(vk + off + 64 * (size_t)i);
+  off += (size_t)nk * 64;
+  if (be32(vk + off) != 1 || be32(vk + off + 4) != 0 || be32(vk + off + 8) != 1) return fail(SPP_ERR_FORMAT, "unsupported commitment layout");
+  const G2Affine pedG = g2_from_raw(vk + off + 12), pedGS = g2_from_raw(vk + off + 12 + 128);
+  for (const G2Affine* q : {&beta2, &gamma2, &delta2, &pedG, &pedGS})
+    if (q->is_inf() || !g2_on_curve(*q)) return fail(SPP_ERR_FORMAT, "verifying key holds an invalid G2 point");
+  if (!pairing_fast_consts_consistent()) return fail(SPP_ERR_HIP, "internal: Frobenius constants are not two-term");
+
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  // per-key preparation on the host: line tables of the four key-side G2 points, e(-alpha, beta), constants
+  VerifyKeyDev h;
+  h.pc = make_pairing_fast_consts();
+  h.e_alpha_beta = f12_from(miller_loop(alpha1.neg(), beta2));
+  h.twist_b = twist_b();
+  h.nk = nk;
+  DevBuf dtab[4], dK, dvk, dproofs, dpws, dok;
+  const G2Affine* qs[4] = {&gamma2, &delta2, &pedG, &pedGS};
+  std::vector<LineStep> tabs_host[4];   // stay alive until the stream has been synchronised
+  for (int k = 0; k < 4; k++) {
+    tabs_host[k] = build_line_table(*qs[k]);
+    UP(dtab[k], tabs_host[k].data(), tabs_host[k].size() * sizeof(LineStep));
+    h.tab[k] = dtab[k].as<LineStep>();
+  }
+  UP(dK, K.data(), K.size() * sizeof(G1Affine));
+  h.K = dK.as<G1Affine>();
+  UP(dvk, &h, sizeof h);
+  UP(dproofs, proofs, count * (size_t)SPP_PROOF_LEN);
+  UP(dpws, pws, count * pw_len);
+  HIP_TRY(dok.alloc(count * sizeof(int32_t)));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  hipEventRecord(e0, st);
+  launch_verify(st, dvk.as<VerifyKeyDev>(), dproofs.as<uint8_t>(), dpws.as<uint8_t>(), (uint32_t)pw_len, (uint32_t)count, dok.as<int32_t>());
+  hipEventRecord(e1, st);
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipGetLastError());
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  if (kernel_ms) *kernel_ms = ms;
+  HIP_TRY(hipMemcpy(ok, dok.p, count * sizeof(int32_t), hipMemcpyDeviceToHost));
   return SPP_OK;
 }
 

@@ -63,6 +63,19 @@ class Context:
         check(self.L.spp_msm_g1_pippenger(self.h, bases_bytes, sc, len(scalars), ctypes.cast(out, ctypes.c_void_p)))
         return out.raw
 
+    def verify_batch(self, vk, proofs, pws, want_ms=False):
+        """`sunspot verify` for many proofs against one key, on the GPU (spp_verify_batch). proofs / pws: lists of bytes.
+        Returns a list of booleans (and the kernel time in ms when want_ms)."""
+        count = len(proofs)
+        assert count == len(pws)
+        pw_len = len(pws[0]) if count else 12
+        ok = (ctypes.c_int32 * max(count, 1))()
+        ms = ctypes.c_float(0)
+        check(self.L.spp_verify_batch(self.h, vk, len(vk), count, b"".join(proofs), b"".join(pws), pw_len,
+                                      ctypes.cast(ok, ctypes.c_void_p), ctypes.byref(ms)))
+        res = [bool(ok[i]) for i in range(count)]
+        return (res, ms.value) if want_ms else res
+
     def msm_g1_pippenger_bench(self, n, seed=5, scale=None, iters=1, small_permille=0):
         """Returns (result bytes, ms per MSM, ms of the bucket kernel). small_permille: share of byte-sized scalars."""
         out = ctypes.create_string_buffer(64)

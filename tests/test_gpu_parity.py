@@ -178,6 +178,51 @@ def test_full_size_batch_is_consistent_with_small_batches(withdraw_handle, withd
         assert rc == 0 and proofs[i] == proof and pws[i] == pw
 
 
+def test_batched_verifier_matches_the_single_proof_verifiers(ctx, withdraw_handle, withdraw_artifacts, audit_artifacts, withdraw_kat, rlwe_pk):
+    """spp_verify_batch on real proofs of both circuits: accepts what the oracle and the host verifier
+    accept, and rejects -- lane by lane -- a flipped byte in each proof element, a wrong public input, a proof checked
+    against another statement, a missing commitment count and the all-zero proof of a refused row."""
+    import spp
+    from oracle import groth16
+    rows = _withdraw_variants(withdraw_kat, 5)
+    rs = [(900 + i, 1900 + 3 * i) for i in range(5)]
+    proofs, pws, status = withdraw_handle.prove_batch(rows, rs)
+    assert status == [0] * 5
+    vk = open(withdraw_artifacts["vk"], "rb").read()
+    cases, expect = [], []
+    for pr, pw in zip(proofs, pws):
+        cases.append((pr, pw)); expect.append(True)
+    def flip(b, i):
+        x = bytearray(b); x[i] ^= 1; return bytes(x)
+    for off in (0, 40, 70, 130, 200, 259, 270, 330, 387):      # Ar.x, Ar.y, Bs, Bs, Krs, commitment count, Cm, PoK, PoK
+        cases.append((flip(proofs[0], off), pws[0])); expect.append(False)
+    cases.append((proofs[1], flip(pws[1], 12 + 31))); expect.append(False)     # root
+    cases.append((proofs[1], flip(pws[1], 12 + 32 * 3 + 31))); expect.append(False)   # amount
+    cases.append((proofs[1], flip(pws[1], 3))); expect.append(False)           # header
+    cases.append((proofs[2], pws[3])); expect.append(False)                    # another statement's inputs
+    cases.append((bytes(388), pws[0])); expect.append(False)                   # refused row
+    got = ctx.verify_batch(vk, [c[0] for c in cases], [c[1] for c in cases])
+    assert got == expect
+    for (pr, pw), e in list(zip(cases, expect))[:8]:
+        assert groth16.verify(vk, pr, pw) == e and spp.verify(vk, pr, pw) == e
+    assert ctx.verify_batch(vk, [], []) == []
+    # a batch larger than a wavefront, mixed
+    big_p = [proofs[i % 5] if i % 7 else flip(proofs[i % 5], 100) for i in range(150)]
+    big_w = [pws[i % 5] for i in range(150)]
+    assert ctx.verify_batch(vk, big_p, big_w) == [bool(i % 7) for i in range(150)]
+    # audit circuit (2 public inputs, 1104-byte key)
+    ha = ctx.load_circuit(audit_artifacts["sppc"], audit_artifacts["pk"], 6)
+    try:
+        arows = _audit_rows(rlwe_pk, 2)
+        ap, aw, ast = ha.prove_batch(arows, [(5, 6), (7, 8)])
+        assert ast == [0, 0]
+    finally:
+        ha.close()
+    avk = open(audit_artifacts["vk"], "rb").read()
+    assert ctx.verify_batch(avk, ap + [ap[0]], aw + [aw[1]]) == [True, True, False]
+    assert groth16.verify(avk, ap[0], aw[0])
+
+
 def test_load_errors_are_reported(ctx, tmp_path, withdraw_artifacts, audit_artifacts):
     """Error behaviour at the boundary (negative codes + message, mapped to thrown errors by the addon)."""
     import spp

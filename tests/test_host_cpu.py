@@ -272,3 +272,81 @@ def test_withdraw_reference_shape_circuit(tmp_path, withdraw_kat):
     assert C.first_unsatisfied(c, C.solve(c, good, chal)) == -1
     bad = list(good); bad[0] += 1
     assert C.first_unsatisfied(c, C.solve(c, bad, chal)) >= 0
+
+
+def test_batched_verifier_pairing_path_host_check(tmp_path):
+    """csrc/pairing_fast.hpp (what the GPU verifier runs: shared Miller loop over per-key line tables, projective lines
+    for the proof's G2 point, x-power final exponentiation) against the single-proof host pairing, compiled for the host."""
+    exe = str(tmp_path / "pairing_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "shielded-pool-pinocchio-solana_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "host", "pairing_check.cpp"), "-o", exe], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert out.strip().splitlines()[-1].startswith("OK "), out
+
+
+def test_verifiers_reject_bs_outside_the_subgroup(withdraw_artifacts, withdraw_kat):
+    """A point on the twist but outside the order-r subgroup in the Bs slot is refused by the oracle and by the product's
+    host verifier before any pairing (the twist's cofactor is ~2^254)."""
+    import spp
+    from oracle import native, groth16, bn254 as B, circuit as C
+    p = native.Prover(withdraw_artifacts["sppc"], withdraw_artifacts["pk"])
+    row = C.withdraw_inputs(withdraw_kat)
+    rc, proof, pw = p.prove(row, 3, 4)
+    vk = open(withdraw_artifacts["vk"], "rb").read()
+    assert rc == 0 and groth16.verify(vk, proof, pw) and spp.verify(vk, proof, pw)
+    # find a twist point with small x: y^2 = x^3 + b'  (square root in Fq2, p = 3 mod 4)
+    P = B.P
+
+    def fq_sqrt(v):
+        r = pow(v, (P + 1) // 4, P)
+        return r if r * r % P == v % P else None
+
+    def fq2_sqrt(a):
+        alpha = fq_sqrt((a[0] * a[0] + a[1] * a[1]) % P)
+        if alpha is None:
+            return None
+        for d in ((a[0] + alpha) * pow(2, -1, P) % P, (a[0] - alpha) * pow(2, -1, P) % P):
+            x0 = fq_sqrt(d)
+            if x0:
+                y = (x0, a[1] * pow(2 * x0, -1, P) % P)
+                if B.f2_mul(y, y) == (a[0] % P, a[1] % P):
+                    return y
+        return None
+    x = 1
+    pt = None
+    while pt is None:
+        x += 1
+        rhs = B.f2_add(B.f2_mul(B.f2_mul((x, 0), (x, 0)), (x, 0)), B.G2_B)
+        y = fq2_sqrt(rhs)
+        if y is not None:
+            pt = ((x, 0), y)
+    assert B.g2_is_on_curve(pt) and groth16._g2_times_r(pt) is not None
+    forged = proof[:64] + B.g2_to_bytes(pt) + proof[192:]
+    assert not groth16.verify(vk, forged, pw)
+    assert not spp.verify(vk, forged, pw)
+
+
+def test_no_return_address_clobber_in_verifier_device_code(tmp_path):
+    """Codegen hazard met on gfx950 / ROCm 7.2: in a large LEAF device function whose loop back-edges
+    need long branches, the branch relaxation used s[30:31] -- the live return address -- for s_getpc/s_setpc, and the
+    function never returned.  The verifier's out-of-line functions are structured to avoid it; this scans the gfx950
+    assembly of kernels_verify.hip for the pattern."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    csrc = os.path.join(ROOT, "shielded-pool-pinocchio-solana_amd", "csrc")
+    asm = str(tmp_path / "kv.s")
+    subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-S", "--cuda-device-only",
+                    "-o", asm, os.path.join(csrc, "kernels_verify.hip")], check=True, stderr=subprocess.DEVNULL)
+    txt = open(asm).read()
+    kernels = set(re.findall(r"\.amdhsa_kernel (\S+)", txt))
+    offenders = []
+    for name in re.findall(r"^(_Z\w+):", txt, re.M):
+        if name in kernels:
+            continue
+        body = txt.split(name + ":", 1)[1]
+        body = body[:body.find(".Lfunc_end")]
+        if re.search(r"s_getpc_b64 s\[30:31\]", body):
+            offenders.append(name)
+    assert not offenders, offenders
