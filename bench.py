@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--window", type=int, default=int(os.environ.get("SPP_WINDOW", "0")), help="MSM window bits; 0 = auto (largest tables within the HBM budget)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the second circuit")
+    ap.add_argument("--no-single", action="store_true", help="skip the single-proof latency leg (keeps profiler per-kernel averages clean)")
     ap.add_argument("--no-refshape", action="store_true", help="skip the withdraw circuit padded to the reference's R1CS size")
     args = ap.parse_args()
 
@@ -200,7 +201,7 @@ def main():
         # SURVEY 8d Config 2: ONE withdraw proof from the reference's own inputs (client/prover-params.toml, committed as
         # tests/golden/withdraw_kat.json), end to end on the device-resident entry point: latency, and proofs/s at batch 1
         single = None
-        if rank == 0 and circuit == "withdraw":
+        if rank == 0 and circuit == "withdraw" and not args.no_single:
             from oracle import circuit as OC
             kat_row = OC.withdraw_inputs(json.load(open(os.path.join(ROOT, "tests", "golden", "withdraw_kat.json"))))
             one_in = torch.frombuffer(bytearray(b"".join(int(v).to_bytes(32, "big") for v in kat_row)), dtype=torch.uint8).to(dev)
