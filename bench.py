@@ -201,9 +201,17 @@ def main():
         # SURVEY 8d Config 2: ONE withdraw proof from the reference's own inputs (client/prover-params.toml, committed as
         # tests/golden/withdraw_kat.json), end to end on the device-resident entry point: latency, and proofs/s at batch 1
         single = None
-        if rank == 0 and circuit == "withdraw" and not args.no_single:
-            from oracle import circuit as OC
-            kat_row = OC.withdraw_inputs(json.load(open(os.path.join(ROOT, "tests", "golden", "withdraw_kat.json"))))
+        if rank == 0 and circuit in ("withdraw", "audit") and not args.no_single:
+            if circuit == "withdraw":
+                from oracle import circuit as OC
+                kat_row = OC.withdraw_inputs(json.load(open(os.path.join(ROOT, "tests", "golden", "withdraw_kat.json"))))
+                kat_name = "client/prover-params.toml (tests/golden/withdraw_kat.json)"
+            else:   # SURVEY 8d Config 1: the reference's own run, sk = 12345, Random(999) (scripts/generate_audit.py:469-470)
+                import random
+                from oracle import rlwe
+                pkj = json.load(open(os.path.join(ROOT, "tests", "golden", "rlwe_pk.json")))
+                kat_row = rlwe.audit_input_vector(rlwe.audit_inputs(pkj["a"], pkj["b"], 12345, random.Random(999)))
+                kat_name = "scripts/generate_audit.py defaults: sk = 12345, Random(999), demo rlwe_pk.json"
             one_in = torch.frombuffer(bytearray(b"".join(int(v).to_bytes(32, "big") for v in kat_row)), dtype=torch.uint8).to(dev)
             one_rs = torch.frombuffer(bytearray((5).to_bytes(32, "big") + (6).to_bytes(32, "big")), dtype=torch.uint8).to(dev)
             one_pr = torch.zeros(388, dtype=torch.uint8, device=dev)
@@ -219,7 +227,7 @@ def main():
             assert int(one_st.item()) == 0
             assert spp.verify(open(vkp, "rb").read(), one_pr.cpu().numpy().tobytes(), one_pw.cpu().numpy().tobytes())
             lat = sorted(lat[2:])
-            single = {"inputs": "client/prover-params.toml (tests/golden/withdraw_kat.json)", "latency_ms_median": round(lat[len(lat) // 2], 3),
+            single = {"inputs": kat_name, "latency_ms_median": round(lat[len(lat) // 2], 3),
                       "latency_ms_min": round(lat[0], 3), "proofs_per_s_at_batch_1": round(1e3 / lat[len(lat) // 2], 2)}
 
         out = None
