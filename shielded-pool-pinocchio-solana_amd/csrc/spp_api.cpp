@@ -954,21 +954,46 @@ extern "C" int spp_prove_batch(spp_circuit* c, size_t count, const uint8_t* inpu
   }
   std::vector<uint32_t> st(count);
   {
+    // Large host batches are cut into chunks that alternate between the two workspaces / proving streams, so the
+    // copies and the solver of chunk k+1 overlap the MSMs of chunk k exactly as consecutive spp_prove_batch_device calls
+    // do, and the workspaces never grow beyond one chunk.
     std::lock_guard<std::mutex> lk(c->ctx->mu);
     HIP_TRY(hipSetDevice(c->ctx->device));
-    Workspace& w = c->ws[c->next_ws];
-    c->last_ws = c->next_ws;
-    c->next_ws ^= 1;
-    if (int e = ensure_workspace(c, w, count)) return e;
-    hipStream_t s = w.st;
-    const size_t nin = c->circ.n_inputs(), npub = c->circ.n_public - 1;
-    HIP_TRY(hipMemcpyAsync(w.d_inputs, inputs, nin * 32 * count, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(w.d_rs, rs, 64 * count, hipMemcpyHostToDevice, s));
-    if (int e = prove_on_device(c, w, (uint32_t)count, w.d_inputs, w.d_rs, w.d_proofs, w.d_pws, w.d_status)) return e;
-    HIP_TRY(hipMemcpyAsync(proofs, w.d_proofs, (size_t)SPP_PROOF_LEN * count, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(pws, w.d_pws, (12 + 32 * npub) * count, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(st.data(), w.d_status, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    const size_t pref = c->circ.n_wires <= 16384 ? 2048 : 512;   // the batch sizes the window tables / slices are tuned for
+    const size_t chunk = count <= pref + pref / 2 ? count : pref;
+    const size_t nin = c->circ.n_inputs(), npub = c->circ.n_public - 1, pwl = 12 + 32 * npub;
+    // copies back to pageable host memory block the caller until their stream has drained, so the results of chunk k are
+    // fetched only after chunk k+1 has been enqueued on the other stream
+    auto fetch = [&](Workspace& w, size_t off, size_t n) -> int {
+      hipStream_t s = w.st;
+      HIP_TRY(hipMemcpyAsync(proofs + (size_t)SPP_PROOF_LEN * off, w.d_proofs, (size_t)SPP_PROOF_LEN * n, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipMemcpyAsync(pws + pwl * off, w.d_pws, pwl * n, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipMemcpyAsync(st.data() + off, w.d_status, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      return 0;
+    };
+    Workspace* prev_w = nullptr;
+    size_t prev_off = 0, prev_n = 0;
+    for (size_t off = 0; off < count; off += chunk) {
+      const size_t n = std::min(chunk, count - off);
+      Workspace& w = c->ws[c->next_ws];
+      c->last_ws = c->next_ws;
+      c->next_ws ^= 1;
+      if (int e = ensure_workspace(c, w, n)) return e;
+      hipStream_t s = w.st;
+      HIP_TRY(hipMemcpyAsync(w.d_inputs, inputs + nin * 32 * off, nin * 32 * n, hipMemcpyHostToDevice, s));
+      HIP_TRY(hipMemcpyAsync(w.d_rs, rs + 64 * off, 64 * n, hipMemcpyHostToDevice, s));
+      if (int e = prove_on_device(c, w, (uint32_t)n, w.d_inputs, w.d_rs, w.d_proofs, w.d_pws, w.d_status)) return e;
+      if (prev_w)
+        if (int e = fetch(*prev_w, prev_off, prev_n)) return e;
+      prev_w = &w;
+      prev_off = off;
+      prev_n = n;
+    }
+    if (prev_w)
+      if (int e = fetch(*prev_w, prev_off, prev_n)) return e;
+    HIP_TRY(hipStreamSynchronize(c->ws[0].st));
+    HIP_TRY(hipStreamSynchronize(c->ws[1].st));
   }
   int rc = SPP_OK;
   for (size_t i = 0; i < count; i++) {

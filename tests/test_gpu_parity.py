@@ -223,6 +223,31 @@ def test_batched_verifier_matches_the_single_proof_verifiers(ctx, withdraw_handl
     assert groth16.verify(avk, ap[0], aw[0])
 
 
+def test_large_host_batch_is_chunked_and_pipelined(withdraw_handle, withdraw_kat):
+    """spp_prove_batch cuts a host batch larger than 1.5 x 2048 into chunks alternating between the two workspaces: results
+    must land at the right offsets (position-dependent blinding), including a refused row in the last, partial chunk."""
+    rows4 = _withdraw_variants(withdraw_kat, 4)
+    n = 2 * 2048 + 700
+    rows = [rows4[i % 4] for i in range(n)]
+    rs = [(1 + (i % 5), 2 + (i % 3)) for i in range(n)]
+    bad_at = n - 13
+    rows[bad_at] = [rows[bad_at][0] + 1] + rows[bad_at][1:]
+    proofs, pws, status = withdraw_handle.prove_batch(rows, rs)
+    assert status[bad_at] != 0 and sum(1 for v in status if v) == 1
+    ref = {}
+    small_rows, small_rs, keys = [], [], []
+    for i in range(60):                      # every (row, blinding) combination occurs within the first 60 positions
+        keys.append((i % 4, rs[i]))
+        small_rows.append(rows4[i % 4]); small_rs.append(rs[i])
+    sp, sw, sst = withdraw_handle.prove_batch(small_rows, small_rs)
+    assert sst == [0] * 60
+    for k, pr, pw in zip(keys, sp, sw):
+        ref[k] = (pr, pw)
+    for i in range(n):
+        if i != bad_at:
+            assert (proofs[i], pws[i]) == ref[(i % 4, rs[i])], i
+
+
 def test_load_errors_are_reported(ctx, tmp_path, withdraw_artifacts, audit_artifacts):
     """Error behaviour at the boundary (negative codes + message, mapped to thrown errors by the addon)."""
     import spp
