@@ -163,6 +163,51 @@ static napi_value ProveBatch(napi_env env, napi_callback_info info) {
   napi_set_named_property(env, out, "status", st);
   return out;
 }
+/* verify(vk Buffer, proof Buffer, publicWitness Buffer) -> boolean   (`sunspot verify`, prove_linux.sh:86-87; host only) */
+static napi_value Verify(napi_env env, napi_callback_info info) {
+  size_t argc = 3;
+  napi_value argv[3];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  void *vk, *pr, *pw;
+  size_t vkl, prl, pwl;
+  NAPI_OK(napi_get_buffer_info(env, argv[0], &vk, &vkl));
+  NAPI_OK(napi_get_buffer_info(env, argv[1], &pr, &prl));
+  NAPI_OK(napi_get_buffer_info(env, argv[2], &pw, &pwl));
+  int ok = 0;
+  int rc = spp_verify((const uint8_t*)vk, vkl, (const uint8_t*)pr, prl, (const uint8_t*)pw, pwl, &ok);
+  if (rc) return throw_spp(env, rc);
+  napi_value r;
+  napi_get_boolean(env, ok != 0, &r);
+  return r;
+}
+/* verifyBatch(vk Buffer, count, proofs Buffer, publicWitnesses Buffer) -> boolean[]   (after init(); one GPU lane per proof) */
+static napi_value VerifyBatch(napi_env env, napi_callback_info info) {
+  size_t argc = 4;
+  napi_value argv[4];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (!g_ctx) { napi_throw_error(env, NULL, "call init() first"); return NULL; }
+  void* ctx = g_ctx;
+  void *vk, *pr, *pw;
+  size_t vkl, prl, pwl;
+  NAPI_OK(napi_get_buffer_info(env, argv[0], &vk, &vkl));
+  uint32_t count = 0;
+  napi_get_value_uint32(env, argv[1], &count);
+  NAPI_OK(napi_get_buffer_info(env, argv[2], &pr, &prl));
+  NAPI_OK(napi_get_buffer_info(env, argv[3], &pw, &pwl));
+  if (prl != (size_t)count * SPP_PROOF_LEN || (count && pwl % count)) {
+    napi_throw_error(env, NULL, "libspp error -1: proof / public-witness buffer has the wrong length");
+    return NULL;
+  }
+  int32_t* ok = (int32_t*)calloc(count ? count : 1, sizeof(int32_t));
+  int rc = spp_verify_batch((spp_ctx*)ctx, (const uint8_t*)vk, vkl, count, (const uint8_t*)pr, (const uint8_t*)pw, count ? pwl / count : 12, ok,
+                            NULL);
+  if (rc) { free(ok); return throw_spp(env, rc); }
+  napi_value arr;
+  napi_create_array_with_length(env, count, &arr);
+  for (uint32_t i = 0; i < count; i++) { napi_value v; napi_get_boolean(env, ok[i] != 0, &v); napi_set_element(env, arr, i, v); }
+  free(ok);
+  return arr;
+}
 static napi_value Version(napi_env env, napi_callback_info info) {
   (void)info;
   napi_value r;
@@ -178,6 +223,8 @@ static napi_value ModuleInit(napi_env env, napi_value exports) {
       {"loadCircuit", NULL, LoadCircuit, NULL, NULL, NULL, napi_default, NULL},
       {"circuitInfo", NULL, CircuitInfo, NULL, NULL, NULL, napi_default, NULL},
       {"proveBatch", NULL, ProveBatch, NULL, NULL, NULL, napi_default, NULL},
+      {"verify", NULL, Verify, NULL, NULL, NULL, napi_default, NULL},
+      {"verifyBatch", NULL, VerifyBatch, NULL, NULL, NULL, napi_default, NULL},
       {"version", NULL, Version, NULL, NULL, NULL, napi_default, NULL},
   };
   napi_define_properties(env, exports, sizeof d / sizeof d[0], d);

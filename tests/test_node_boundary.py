@@ -32,16 +32,36 @@ def test_addon_exports_and_prover_toml(addon, withdraw_kat, tmp_path):
       const h = require(%s);
       const inputs = %s;
       process.stdout.write(JSON.stringify({
-        fns: ['init','buildCircuit','setup','loadCircuit','circuitInfo','proveBatch','version'].map(n => typeof h.addon[n]),
+        fns: ['init','buildCircuit','setup','loadCircuit','circuitInfo','proveBatch','verify','verifyBatch','version'].map(n => typeof h.addon[n]),
         version: h.addon.version(), toml: h.proverToml(inputs), n: h.addon.buildCircuit(1, %s),
         amount: h.toField32(inputs.amount).toString('hex') }));
     """ % (json.dumps(addon), json.dumps({f: k[f] for f in fields}), json.dumps(str(tmp_path / "w.sppc")))
     r = _node(script)
     assert r.returncode == 0, r.stderr
     out = json.loads(r.stdout)
-    assert out["fns"] == ["function"] * 7 and out["version"].startswith("libspp")
+    assert out["fns"] == ["function"] * 9 and out["version"].startswith("libspp")
     assert out["toml"] == prover_toml(ShieldedPoolInputs(**{f: k[f] for f in fields}))     # proof.helper.ts:32-50
     assert out["n"] > 5000 and int(out["amount"], 16) == k["amount"]
+
+
+def test_addon_verify_on_host(addon, withdraw_artifacts, withdraw_kat):
+    """addon.verify = `sunspot verify` (prove_linux.sh:86-87): accepts an oracle proof, rejects a flipped byte; no GPU."""
+    from oracle import native, circuit as C
+    p = native.Prover(withdraw_artifacts["sppc"], withdraw_artifacts["pk"])
+    rc, proof, pw = p.prove(C.withdraw_inputs(withdraw_kat), 21, 22)
+    assert rc == 0
+    vk = open(withdraw_artifacts["vk"], "rb").read()
+    bad = bytearray(proof); bad[5] ^= 1
+    script = """
+      const h = require(%s);
+      const vk = Buffer.from(%s, 'hex'), pr = Buffer.from(%s, 'hex'), bad = Buffer.from(%s, 'hex'), pw = Buffer.from(%s, 'hex');
+      let threw = false;
+      try { h.addon.verify(vk, pr.slice(0, 100), pw); } catch (e) { threw = /libspp error -7/.test(e.message); }
+      process.stdout.write(JSON.stringify({ok: h.addon.verify(vk, pr, pw), bad: h.addon.verify(vk, bad, pw), threw}));
+    """ % (json.dumps(addon), json.dumps(vk.hex()), json.dumps(proof.hex()), json.dumps(bytes(bad).hex()), json.dumps(pw.hex()))
+    r = _node(script)
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout) == {"ok": True, "bad": False, "threw": True}
 
 
 def test_generate_proof_hex_twins_agree(tmp_path):
@@ -77,14 +97,19 @@ def test_generate_proof_through_node_on_gpu(addon, withdraw_artifacts, withdraw_
       const r = h.generateProof({circuitDir: %s, circuitName: 'shielded_pool_verifier'}, %s);
       let threw = false;
       try { h.generateProof({circuitDir: %s, circuitName: 'shielded_pool_verifier'}, Object.assign({}, %s, {recipient: '0x0'})); } catch (e) { threw = /libspp error -4/.test(e.message); }
-      process.stdout.write(JSON.stringify({proof: r.proof.toString('hex'), pw: r.publicWitness.toString('hex'), threw}));
+      const fs = require('fs');
+      const vk = fs.readFileSync(%s);
+      const badp = Buffer.from(r.proof); badp[9] ^= 1;
+      const vb = h.addon.verifyBatch(vk, 2, Buffer.concat([r.proof, badp]), Buffer.concat([r.publicWitness, r.publicWitness]));
+      process.stdout.write(JSON.stringify({proof: r.proof.toString('hex'), pw: r.publicWitness.toString('hex'), threw, vb}));
     """ % (json.dumps(addon), json.dumps(str(cdir)), json.dumps({f: withdraw_kat[f] for f in fields}), json.dumps(str(cdir)),
-           json.dumps({f: withdraw_kat[f] for f in fields}))
+           json.dumps({f: withdraw_kat[f] for f in fields}), json.dumps(withdraw_artifacts["vk"]))
     r = _node(script)
     assert r.returncode == 0, r.stderr
     out = json.loads(r.stdout)
     proof, pw = bytes.fromhex(out["proof"]), bytes.fromhex(out["pw"])
     assert len(proof) == 388 and len(pw) == 172 and out["threw"]
+    assert out["vb"] == [True, False]                     # addon.verifyBatch on the GPU
     assert (cdir / "target" / "shielded_pool_verifier.proof").read_bytes() == proof
     assert (cdir / "Prover.toml").exists()
     assert groth16.verify(open(withdraw_artifacts["vk"], "rb").read(), proof, pw)
