@@ -350,3 +350,25 @@ def test_no_return_address_clobber_in_verifier_device_code(tmp_path):
         if re.search(r"s_getpc_b64 s\[30:31\]", body):
             offenders.append(name)
     assert not offenders, offenders
+
+
+def test_committed_bench_line_follows_the_contract():
+    """The bench line committed under profiles/ (the output of `python bench.py` on the MI355X box) carries every field
+    of the driver's contract, the roofline object and the CPU baseline, with consistent arithmetic."""
+    import glob
+    import json
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "round1_*_bench_default_run.json")))
+    assert paths
+    j = json.load(open(paths[-1]))
+    for k, t in (("metric", str), ("value", (int, float)), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                 ("ms_per_step", (int, float)), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict)):
+        assert isinstance(j[k], t), k
+    assert j["vs_baseline"] is None and j["scaling"] == "weak" and j["higher_is_better"] is True and "workload" in j["config"]
+    assert abs(j["value"] - j["config"]["batch_per_gpu"] * j["n_gpus"] / (j["ms_per_step"] * 1e-3)) / j["value"] < 0.01
+    r = j["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5
+    assert abs(r["achieved"] - r["alg_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 0.01
+    assert r["traffic"] is None or r["traffic"] > r["alg_bytes_per_launch"]
+    c = j["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == j["unit"] and c["sample"]
