@@ -39,6 +39,9 @@ struct DevCircuit {
   const Fr* pos5_rc;  const Fr* pos5_mds;   // t=5: 340 rc, 25 mds
   const Fr* p2_rc;    const Fr* p2_mu;      // 88 rc, 4 mu
   const Fr* byte_mont;                      // Montgomery forms of 0..255
+  // Poseidon MDS matrices in the 9x29-bit form, scaled by 2^261 (f29.hpp): mont29(state word, entry) stays an x*2^256 word
+  const uint32_t* pos3_mds29;               // 9 x 9 limbs
+  const uint32_t* pos5_mds29;               // 25 x 9 limbs
 };
 
 // Poseidon / Poseidon2 constants in HBM (Montgomery form), shared by the solver and the stand-alone hash kernels

@@ -17,6 +17,7 @@
 #include "circuit.hpp"
 #include "kernels.hpp"
 #include "sha256.hpp"
+#include "f29.hpp"
 #include "pairing.hpp"
 #include "pairing_fast_host.hpp"
 
@@ -583,7 +584,11 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
     const Poseidon2Params& p2 = poseidon2_params();
     Fr *a, *b, *cc, *d, *f, *g;
     std::vector<Fr> mu(p2.mu, p2.mu + 4);
-    if ((e = own_upload(c, &a, p3.rc)) || (e = own_upload(c, &b, flat(p3))) || (e = own_upload(c, &cc, p5.rc)) ||
+    auto canon = [](std::vector<Fr> v) {   // words < p: dev_poseidon29's value bounds rely on it
+      for (auto& x : v) x = x.canonical();
+      return v;
+    };
+    if ((e = own_upload(c, &a, canon(p3.rc))) || (e = own_upload(c, &b, flat(p3))) || (e = own_upload(c, &cc, canon(p5.rc))) ||
         (e = own_upload(c, &d, flat(p5))) || (e = own_upload(c, &f, p2.rc)) || (e = own_upload(c, &g, mu)))
       return e;
     std::vector<Fr> bytes(256);
@@ -591,6 +596,19 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
     Fr* bm;
     if ((e = own_upload(c, &bm, bytes))) return e;
     c->dc.byte_mont = bm;
+    auto flat29 = [](const PoseidonParams& pp) {
+      std::vector<uint32_t> m;
+      for (auto& row : pp.mds)
+        for (auto& v : row) {
+          const F29<FrParams> x = F29<FrParams>::from_fp(v);     // v * 2^261, normalised, < 1.1 p
+          for (int k = 0; k < 9; k++) m.push_back(x.l[k]);
+        }
+      return m;
+    };
+    uint32_t *m3, *m5;
+    if ((e = own_upload(c, &m3, flat29(p3))) || (e = own_upload(c, &m5, flat29(p5)))) return e;
+    c->dc.pos3_mds29 = m3;
+    c->dc.pos5_mds29 = m5;
     c->dc.pos3_rc = a; c->dc.pos3_mds = b; c->dc.pos5_rc = cc; c->dc.pos5_mds = d; c->dc.p2_rc = f; c->dc.p2_mu = g;
   }
   // program scan: split into sequential segments (one lane per proof) and wide steps (data-parallel instructions
