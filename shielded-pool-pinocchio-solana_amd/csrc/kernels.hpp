@@ -46,9 +46,11 @@ struct DevCircuit {
 
 // Poseidon / Poseidon2 constants in HBM (Montgomery form), shared by the solver and the stand-alone hash kernels
 struct HashConsts {
-  const Fr* pos3_rc;  const Fr* pos3_mds;
+  const Fr* pos3_rc;  const Fr* pos3_mds;   // rc words canonical (< p): poseidon29.hpp's value bounds rely on it
   const Fr* pos5_rc;  const Fr* pos5_mds;
   const Fr* p2_rc;    const Fr* p2_mu;
+  const uint32_t* pos3_mds29;               // MDS entries * 2^261 in 9 x 29-bit limbs (poseidon29.hpp)
+  const uint32_t* pos5_mds29;
 };
 
 // ---- stand-alone witness-input kernels (kernels_witness.hip) ----

@@ -9,6 +9,7 @@
 //   k_grumpkin_keygen     client/merkle.ts:98-113 (generateIdentityKeypair), main.nr:54-59
 //   k_poseidon2_sponge    ct_helper/src/main.nr:15-34 (= scripts/generate_audit.py:355-374)
 #include "kernels.hpp"
+#include "poseidon29.hpp"
 
 namespace spp {
 
@@ -131,28 +132,14 @@ __device__ __forceinline__ Fr sbox5(const Fr& x) {
   Fr x2 = x.sqr();
   return x2.sqr() * x;
 }
+// the permutation itself lives in poseidon29.hpp (9x29-bit form, lazy MDS rows); nothing is emitted here
 template <int T>
-__device__ __noinline__ void poseidon_permute(Fr (&s)[T], const Fr* __restrict__ rc, const Fr* __restrict__ mds, int rp) {
-  const int rf = 8;
-#pragma unroll 1
-  for (int r = 0; r < rf + rp; r++) {
-    SPP_UNROLL for (int i = 0; i < T; i++) s[i] = s[i] + rc[r * T + i];
-    if (r < rf / 2 || r >= rf / 2 + rp) {
-      SPP_UNROLL for (int i = 0; i < T; i++) s[i] = sbox5(s[i]);
-    } else {
-      s[0] = sbox5(s[0]);
-    }
-    Fr nx[T];
-    SPP_UNROLL for (int i = 0; i < T; i++) {
-      nx[i] = mds[i * T] * s[0];
-      SPP_UNROLL for (int j = 1; j < T; j++) nx[i] = nx[i] + mds[i * T + j] * s[j];
-    }
-    SPP_UNROLL for (int i = 0; i < T; i++) s[i] = nx[i];
-  }
+__device__ __noinline__ void poseidon_permute(Fr (&s)[T], const Fr* __restrict__ rc, const uint32_t* __restrict__ mds29, int rp) {
+  poseidon_permute29<T, false>(s, rc, mds29, rp, PoseidonNoEmit{});
 }
 __device__ __forceinline__ Fr poseidon_hash2(const HashConsts& hc, const Fr& a, const Fr& b) {
   Fr s[3] = {Fr::zero(), a, b};
-  poseidon_permute<3>(s, hc.pos3_rc, hc.pos3_mds, 57);
+  poseidon_permute<3>(s, hc.pos3_rc, hc.pos3_mds29, 57);
   return s[0];
 }
 
@@ -166,7 +153,7 @@ __global__ void __launch_bounds__(64) k_poseidon_hash(HashConsts hc, const uint8
     h = poseidon_hash2(hc, load_be(in), load_be(in + 32));
   } else {
     Fr s[5] = {Fr::zero(), load_be(in), load_be(in + 32), load_be(in + 64), load_be(in + 96)};
-    poseidon_permute<5>(s, hc.pos5_rc, hc.pos5_mds, 60);
+    poseidon_permute<5>(s, hc.pos5_rc, hc.pos5_mds29, 60);
     h = s[0];
   }
   store_be(out_be + (size_t)g * 32, h);

@@ -1347,10 +1347,25 @@ static int ensure_ctx_consts(spp_ctx* ctx) {
   std::vector<Fr> mu(p2.mu, p2.mu + 4);
   Fr *a, *b, *c, *d, *f, *g;
   int e;
-  if ((e = ctx_upload(ctx, &a, p3.rc)) || (e = ctx_upload(ctx, &b, flat(p3))) || (e = ctx_upload(ctx, &c, p5.rc)) ||
-      (e = ctx_upload(ctx, &d, flat(p5))) || (e = ctx_upload(ctx, &f, p2.rc)) || (e = ctx_upload(ctx, &g, mu)))
+  auto canon = [](std::vector<Fr> v) {
+    for (auto& x : v) x = x.canonical();
+    return v;
+  };
+  auto flat29 = [](const PoseidonParams& pp) {
+    std::vector<uint32_t> m;
+    for (auto& row : pp.mds)
+      for (auto& v : row) {
+        const F29<FrParams> x = F29<FrParams>::from_fp(v);
+        for (int k = 0; k < 9; k++) m.push_back(x.l[k]);
+      }
+    return m;
+  };
+  uint32_t *m3, *m5;
+  if ((e = ctx_upload(ctx, &a, canon(p3.rc))) || (e = ctx_upload(ctx, &b, flat(p3))) || (e = ctx_upload(ctx, &c, canon(p5.rc))) ||
+      (e = ctx_upload(ctx, &d, flat(p5))) || (e = ctx_upload(ctx, &f, p2.rc)) || (e = ctx_upload(ctx, &g, mu)) ||
+      (e = ctx_upload(ctx, &m3, flat29(p3))) || (e = ctx_upload(ctx, &m5, flat29(p5))))
     return e;
-  ctx->hc = HashConsts{a, b, c, d, f, g};
+  ctx->hc = HashConsts{a, b, c, d, f, g, m3, m5};
   // Grumpkin window table T[j][d] = (d+1) * 16^j * G, j < 64, d < 16
   std::vector<GkAffine> tab(64 * 16);
   GkXYZZ base = GkXYZZ::from_affine(grumpkin_generator());
