@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)    # SURVEY 8d timing rule: warm-up 3, >= 10 iterations or >= 2 s
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=0, help="proofs per GPU per step (0 = 2048 for withdraw, 512 for audit)")
+    ap.add_argument("--batch", type=int, default=0, help="proofs per GPU per step (0 = 4096 for withdraw, 2048 for audit)")
     ap.add_argument("--circuit", default=os.environ.get("SPP_BENCH_CIRCUIT", "withdraw"), choices=["withdraw", "audit"])
     ap.add_argument("--window", type=int, default=int(os.environ.get("SPP_WINDOW", "0")), help="MSM window bits; 0 = auto (largest tables within the HBM budget)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -302,7 +302,7 @@ def main():
         torch.cuda.empty_cache()
         return out
 
-    default_batch = {"withdraw": 2048, "audit": 512, "withdraw_refshape": 1024}
+    default_batch = {"withdraw": 4096, "audit": 2048, "withdraw_refshape": 2048}
     main_res = run_circuit(args.circuit, args.batch or default_batch[args.circuit], args.steps, args.warmup,
                            not args.no_cpu_baseline and world == 1)   # CPU baseline: rank 0 at N=1 only
     # the other circuit of BASELINE.json's metric, as a secondary figure (single GPU runs only)

@@ -977,7 +977,7 @@ extern "C" int spp_prove_batch(spp_circuit* c, size_t count, const uint8_t* inpu
     // do, and the workspaces never grow beyond one chunk.
     std::lock_guard<std::mutex> lk(c->ctx->mu);
     HIP_TRY(hipSetDevice(c->ctx->device));
-    const size_t pref = c->circ.n_wires <= 16384 ? 2048 : 512;   // the batch sizes the window tables / slices are tuned for
+    const size_t pref = c->circ.n_wires <= 16384 ? 4096 : 2048;  // batch sizes at which the per-launch overheads are amortised
     const size_t chunk = count <= pref + pref / 2 ? count : pref;
     const size_t nin = c->circ.n_inputs(), npub = c->circ.n_public - 1, pwl = 12 + 32 * npub;
     // copies back to pageable host memory block the caller until their stream has drained, so the results of chunk k are

@@ -155,16 +155,16 @@ def test_withdraw_proof_bytes_match_oracle_and_verify(withdraw_handle, withdraw_
 
 
 def test_full_size_batch_is_consistent_with_small_batches(withdraw_handle, withdraw_artifacts, withdraw_kat):
-    """BASELINE-size batch (2048 proofs per launch sequence) through a size-independent property: lanes that carry the
+    """Bench-size batch (4096 proofs per launch sequence) through a size-independent property: lanes that carry the
     same inputs and blinding produce the same bytes wherever they sit in the batch, those bytes are the oracle's, and
     one unsatisfiable row in the middle is refused without disturbing its neighbours."""
     from oracle import native
     rows4 = _withdraw_variants(withdraw_kat, 4)
     rs4 = [(31 + i, 57 + 2 * i) for i in range(4)]
-    B_ = 2048
+    B_ = 4096
     rows = [rows4[i % 4] for i in range(B_)]
     rs = [rs4[i % 4] for i in range(B_)]
-    bad_at = 1027
+    bad_at = 3027
     rows[bad_at] = [rows[bad_at][0] + 1] + rows[bad_at][1:]
     proofs, pws, status = withdraw_handle.prove_batch(rows, rs)
     assert status[bad_at] != 0 and proofs[bad_at] == bytes(388)
@@ -224,10 +224,10 @@ def test_batched_verifier_matches_the_single_proof_verifiers(ctx, withdraw_handl
 
 
 def test_large_host_batch_is_chunked_and_pipelined(withdraw_handle, withdraw_kat):
-    """spp_prove_batch cuts a host batch larger than 1.5 x 2048 into chunks alternating between the two workspaces: results
+    """spp_prove_batch cuts a host batch larger than 1.5 x 4096 into chunks alternating between the two workspaces: results
     must land at the right offsets (position-dependent blinding), including a refused row in the last, partial chunk."""
     rows4 = _withdraw_variants(withdraw_kat, 4)
-    n = 2 * 2048 + 700
+    n = 2 * 4096 + 700
     rows = [rows4[i % 4] for i in range(n)]
     rs = [(1 + (i % 5), 2 + (i % 3)) for i in range(n)]
     bad_at = n - 13
