@@ -249,10 +249,12 @@ def main():
             avg_ms = acc["kern_ms"] / max(acc["kern_n"], 1)
             achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             traffic = None
+            valu_util = None
             try:   # PMC pass of the same workload, committed under profiles/ (rocprofv3 --pmc cannot run inside this process)
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_latest.json")))
                 if pmc.get("circuit") == circuit and pmc.get("batch") == B and pmc.get("window_bits") == h.window_bits:
                     traffic = pmc["k_msm_fixed_g1_hbm_bytes_per_launch"]
+                    valu_util = pmc.get("k_msm_fixed_g1_valu_issue_util_serialised")
             except Exception:
                 pass
             out = {
@@ -272,6 +274,7 @@ def main():
                 "roofline": {"bound": "hbm", "kernel": "k_msm_fixed<Fq>", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "alg_bytes_per_launch": int(alg_bytes),
                              "avg_launch_ms": round(avg_ms, 4), "launches_timed": acc["kern_n"],
+                             "valu_issue_util_pmc": valu_util,   # SQ counters of the serialised run of the same workload (profiles/)
                              "note": "integer-VALU bound (about 2.3K instructions, 1.5K of them v_mad_u64_u32, per mixed addition); HBM fraction reported as mandated"},
             }
             if single is not None:
