@@ -25,15 +25,15 @@ sys.path.insert(0, os.path.join(ROOT, "shielded-pool-pinocchio-solana_amd"))
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def synth_withdraw_rows(count, seed=2):
-    """Synthetic, valid withdraw inputs: `count` notes inserted in one depth-16 Poseidon tree
+def synth_withdraw_rows(count, seed=2, depth=16):
+    """Synthetic, valid withdraw inputs: `count` notes inserted in one depth-16 (or depth-20) Poseidon tree
     (client/merkle.ts semantics).  Built with the oracle's pure-Python hashes -- bounded to 8 distinct notes,
     repeated to fill the batch (the GPU work is data-independent)."""
     import random
     from oracle import hashes as H
     rng = random.Random(seed)
     distinct = min(count, 8)
-    tree = H.MerkleTree()
+    tree = H.MerkleTree(depth)
     notes = []
     for _ in range(distinct):
         sk = rng.randrange(1, 1 << 128)
@@ -107,6 +107,8 @@ def main():
             spp.build_circuit(1, sppc)
         elif circuit == "withdraw_refshape":
             spp.build_circuit(3, sppc)       # same statement, padded to the reference's gnark R1CS size (12 452 constraints, 2^14)
+        elif circuit == "withdraw_depth20":
+            spp.build_circuit(4, sppc)       # SURVEY 8d Config 2's synthetic variant: a depth-20 tree (the reference is depth 16)
         else:
             pk = json.load(open(os.path.join(ROOT, "tests", "golden", "rlwe_pk.json")))
             spp.build_circuit(2, sppc, aux=list(pk["a"]) + list(pk["b"]))
@@ -133,7 +135,10 @@ def main():
         load_s = time.time() - t0
 
         # ---- synthetic batch, resident in HBM ----
-        rows = synth_withdraw_rows(B) if circuit.startswith("withdraw") else synth_audit_rows(B)
+        if circuit == "withdraw_depth20":
+            rows = synth_withdraw_rows(B, seed=20, depth=20)
+        else:
+            rows = synth_withdraw_rows(B) if circuit.startswith("withdraw") else synth_audit_rows(B)
         inp = torch.frombuffer(bytearray(b"".join(int(v).to_bytes(32, "big") for r in rows for v in r)), dtype=torch.uint8).to(dev)
         rs_bytes = b"".join((1000003 * (rank * B + i) + 17).to_bytes(32, "big") + (998244353 * (rank * B + i) + 29).to_bytes(32, "big")
                             for i in range(B))
@@ -262,6 +267,7 @@ def main():
                 "config": {"workload": "%s, batch of %d independent proofs per GPU per step" % (
                     {"withdraw": "noir_circuit withdraw (Poseidon Merkle depth 16 + Grumpkin)",
                      "withdraw_refshape": "noir_circuit withdraw padded with ballast multiplications to the reference's gnark R1CS size",
+                     "withdraw_depth20": "withdraw statement over a depth-20 Poseidon tree (synthetic variant; the reference is depth 16)",
                      "audit": "audit_circuit (RLWE, const-PK)"}[circuit], B),
                     "circuit": circuit, "n_constraints": h.n_constraints, "n_wires": h.n_wires, "domain": 1 << h.domain_log,
                     "batch_per_gpu": B, "window_bits": h.window_bits, "msm_windows": dict(zip(["A", "B1", "K", "Z", "CB", "CS", "B2(G2)"], h.msm_windows())), "msm_sizes": dict(zip(["A", "B1", "K", "Z", "CB", "CS", "B2(G2)"], sizes)),
@@ -305,7 +311,7 @@ def main():
         torch.cuda.empty_cache()
         return out
 
-    default_batch = {"withdraw": 4096, "audit": 2048, "withdraw_refshape": 2048}
+    default_batch = {"withdraw": 4096, "audit": 2048, "withdraw_refshape": 2048, "withdraw_depth20": 2048}
     main_res = run_circuit(args.circuit, args.batch or default_batch[args.circuit], args.steps, args.warmup,
                            not args.no_cpu_baseline and world == 1)   # CPU baseline: rank 0 at N=1 only
     # the other circuit of BASELINE.json's metric, as a secondary figure (single GPU runs only)
@@ -317,6 +323,9 @@ def main():
     refshape = None
     if world == 1 and not args.no_refshape and args.circuit == "withdraw":
         refshape = run_circuit("withdraw_refshape", default_batch["withdraw_refshape"], 3, 1, False)
+    depth20 = None
+    if world == 1 and not args.no_refshape and args.circuit == "withdraw":
+        depth20 = run_circuit("withdraw_depth20", default_batch["withdraw_depth20"], 3, 1, False)
     if rank == 0:
         line = {"metric": "Groth16 proofs/sec", "value": main_res["value"], "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
@@ -328,6 +337,8 @@ def main():
             line["secondary_" + ("audit" if args.circuit == "withdraw" else "withdraw") + "_circuit"] = other
         if refshape is not None:
             line["withdraw_at_reference_r1cs_size"] = refshape
+        if depth20 is not None:
+            line["withdraw_depth20_variant"] = depth20
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -49,6 +49,9 @@ extern "C" {
  * reference's gnark R1CS (noir_circuit/target/shielded_pool_verifier.ccs: 12 452 constraints, domain 2^14), for
  * like-for-like throughput figures.  The container it writes is an ordinary SPP_CIRCUIT_WITHDRAW circuit. */
 #define SPP_CIRCUIT_WITHDRAW_REFSHAPE 3
+/* spp_circuit_build only: the withdraw statement over a depth-20 tree (20 siblings, 25 secret inputs) -- the synthetic
+ * variant of SURVEY 8d Config 2 / BASELINE.json configs[1]; the reference's circuit is depth 16 (main.nr:11). */
+#define SPP_CIRCUIT_WITHDRAW_DEPTH20 4
 
 #define SPP_PROOF_LEN 388        /* withdraw.rs:13, submit_audit.rs:18 */
 #define SPP_WITHDRAW_PW_LEN 172  /* withdraw.rs:14-16 */

@@ -495,7 +495,7 @@ std::pair<LC, LC> gadget_grumpkin_fixed_base(Builder& b, const std::vector<LC>& 
 // =====================================================================================================
 // Withdraw circuit: noir_circuit/src/main.nr:38-82
 // =====================================================================================================
-Circuit build_withdraw_circuit(bool native_hints, uint32_t pad_to_constraints) {
+Circuit build_withdraw_circuit(bool native_hints, uint32_t pad_to_constraints, uint32_t depth) {
   Builder b(CIRCUIT_WITHDRAW);
   // public inputs, in the .pw order (withdraw.rs:74-90)
   LC root = b.public_input();
@@ -510,7 +510,7 @@ Circuit build_withdraw_circuit(bool native_hints, uint32_t pad_to_constraints) {
   LC randomness = b.secret_input();
   LC index = b.secret_input();
   std::vector<LC> siblings;
-  for (int i = 0; i < 16; i++) siblings.push_back(b.secret_input());
+  for (uint32_t i = 0; i < depth; i++) siblings.push_back(b.secret_input());   // 16 in the reference (main.nr:11,49)
 
   // 1. secret_key * G == (owner_x, owner_y)        main.nr:52-62
   //    canonical 254-bit decomposition (lo = bits 0..127, hi = bits 128..253)
@@ -535,10 +535,10 @@ Circuit build_withdraw_circuit(bool native_hints, uint32_t pad_to_constraints) {
   // 4. nullifier == Poseidon(secret_key, index)      main.nr:72-74
   b.assert_eq(gadget_poseidon_hash(b, {secret_key, index}, native_hints), nullifier);
 
-  // 5. Merkle membership, depth 16                   main.nr:11-29,76-78
-  std::vector<LC> path = b.to_bits(index, 16);
+  // 5. Merkle membership, depth 16 in the reference  main.nr:11-29,76-78
+  std::vector<LC> path = b.to_bits(index, depth);
   LC cur = commitment;
-  for (int i = 0; i < 16; i++) {
+  for (uint32_t i = 0; i < depth; i++) {
     LC d = b.mul(path[i], siblings[i] - cur);  // bit ? sibling-cur : 0
     LC left = cur + d;
     LC right = siblings[i] - d;

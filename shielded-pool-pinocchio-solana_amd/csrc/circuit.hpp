@@ -314,7 +314,7 @@ std::pair<LC, LC> gadget_grumpkin_fixed_base(Builder& b, const std::vector<LC>& 
 
 GkAffine grumpkin_generator();
 GkAffine grumpkin_offset();
-Circuit build_withdraw_circuit(bool native_hints, uint32_t pad_to_constraints = 0);
+Circuit build_withdraw_circuit(bool native_hints, uint32_t pad_to_constraints = 0, uint32_t depth = 16);
 Circuit build_audit_circuit(const uint32_t* pk_a, const uint32_t* pk_b, bool native_hints);
 
 }  // namespace spp

@@ -337,6 +337,8 @@ extern "C" int spp_circuit_build(int circuit_id, const uint32_t* aux, const char
     c = build_withdraw_circuit(true);
   } else if (circuit_id == SPP_CIRCUIT_WITHDRAW_REFSHAPE) {
     c = build_withdraw_circuit(true, 12452);
+  } else if (circuit_id == SPP_CIRCUIT_WITHDRAW_DEPTH20) {
+    c = build_withdraw_circuit(true, 0, 20);
   } else if (circuit_id == SPP_CIRCUIT_AUDIT) {
     if (!aux) return fail(SPP_ERR_BAD_INPUT, "audit circuit needs the RLWE public key (aux)");
     c = build_audit_circuit(aux, aux + 1024, true);
@@ -1027,6 +1029,7 @@ extern "C" int spp_prove_withdraw(spp_circuit* c, const spp_withdraw_inputs* in,
                                   uint8_t pw[SPP_WITHDRAW_PW_LEN]) {
   if (!c || !in || !proof || !pw) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
   if (c->circ.id != SPP_CIRCUIT_WITHDRAW) return fail(SPP_ERR_BAD_INPUT, "not a withdraw circuit");
+  if (c->circ.n_inputs() != 10 + SPP_TREE_DEPTH) return fail(SPP_ERR_BAD_INPUT, "this entry point serves the depth-16 circuit; use spp_prove_batch");
   std::vector<uint8_t> buf(26 * 32, 0);
   auto put = [&](int i, const uint8_t* v) { memcpy(buf.data() + 32 * i, v, 32); };
   auto put64 = [&](int i, uint64_t v) { for (int k = 0; k < 8; k++) buf[32 * i + 31 - k] = (uint8_t)(v >> (8 * k)); };

@@ -10,6 +10,7 @@ SPP_OK = 0
 SPP_ERR_UNSAT = -4
 SPP_CIRCUIT_WITHDRAW = 1
 SPP_CIRCUIT_AUDIT = 2
+SPP_CIRCUIT_WITHDRAW_DEPTH20 = 4     # build only: withdraw over a depth-20 tree (synthetic variant)
 SPP_CIRCUIT_WITHDRAW_REFSHAPE = 3   # build only: withdraw padded to the reference's R1CS size (12 452 constraints)
 PROOF_LEN = 388
 

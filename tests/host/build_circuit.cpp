@@ -11,6 +11,7 @@ int main(int argc, char** argv) {
   if (!strcmp(argv[1], "withdraw")) c = build_withdraw_circuit(true);
   else if (!strcmp(argv[1], "withdraw-generic")) c = build_withdraw_circuit(false);
   else if (!strcmp(argv[1], "withdraw-refshape")) c = build_withdraw_circuit(true, 12452);
+  else if (!strcmp(argv[1], "withdraw-depth20")) c = build_withdraw_circuit(true, 0, 20);
   else if (!strcmp(argv[1], "audit") || !strcmp(argv[1], "audit-generic")) {
     // argv[3]: text file with 2048 integers (a then b)
     std::vector<uint32_t> pk;

@@ -335,6 +335,34 @@ def test_reference_shape_withdraw_circuit_matches_oracle(ctx, tmp_path, withdraw
         h.close()
 
 
+def test_depth20_withdraw_variant_matches_oracle(ctx, tmp_path):
+    """The depth-20 variant of the withdraw statement (SURVEY 8d Config 2): GPU proof bytes == C oracle, pairing check."""
+    import spp
+    from oracle import native, groth16
+    from test_host_cpu import _depth20_rows
+    sppc, pk, vk = (str(tmp_path / ("w20." + e)) for e in ("sppc", "pk", "vk"))
+    spp.build_circuit(spp.lib.SPP_CIRCUIT_WITHDRAW_DEPTH20, sppc)
+    native.setup(sppc, b"\x14" * 32, pk, vk)
+    os.environ["SPP_TABLE_BUDGET_GB"] = "24"
+    h = ctx.load_circuit(sppc, pk, 0)
+    del os.environ["SPP_TABLE_BUDGET_GB"]
+    try:
+        assert h.n_inputs == 30 and h.domain_log == 14
+        rows = _depth20_rows(3)
+        rs = [(41 + i, 97 + i) for i in range(3)]
+        proofs, pws, status = h.prove_batch(rows, rs)
+        assert status == [0, 0, 0]
+        orc = native.Prover(sppc, pk)
+        for i in range(3):
+            rc, proof, pw = orc.prove(rows[i], rs[i][0], rs[i][1])
+            assert rc == 0 and proofs[i] == proof and pws[i] == pw
+        assert groth16.verify(open(vk, "rb").read(), proofs[1], pws[1])
+        bad = list(rows[2]); bad[10 + 17] += 1
+        assert h.prove_batch([bad], [(1, 2)])[2] != [0]
+    finally:
+        h.close()
+
+
 # ---------------------------------------------------------------------------------------------- audit circuit
 def _audit_rows(rlwe_pk, count):
     from oracle import rlwe

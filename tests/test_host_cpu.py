@@ -372,3 +372,40 @@ def test_committed_bench_line_follows_the_contract():
     assert r["traffic"] is None or r["traffic"] > r["alg_bytes_per_launch"]
     c = j["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == j["unit"] and c["sample"]
+
+
+def _depth20_rows(count):
+    import random
+    from oracle import hashes as H
+    rng = random.Random(2020)
+    tree = H.MerkleTree(20)
+    notes = []
+    for _ in range(count):
+        sk = rng.randrange(1, 1 << 128)
+        owner = H.fixed_base_scalar_mul(sk)
+        amount = rng.randrange(1, 1 << 40)
+        rnd = rng.randrange(1 << 250)
+        idx = tree.insert(H.poseidon_hash4(owner[0], owner[1], amount, rnd))
+        notes.append((sk, owner, amount, rnd, idx))
+    root = tree.root()
+    return [[root, H.poseidon_hash2(sk, idx), rng.randrange(1, 1 << 240), amount, H.poseidon_hash2(owner[0], owner[1]),
+             sk, owner[0], owner[1], rnd, idx] + tree.proof(idx) for sk, owner, amount, rnd, idx in notes]
+
+
+def test_withdraw_depth20_variant_semantics(tmp_path):
+    """SPP_CIRCUIT_WITHDRAW_DEPTH20 (SURVEY 8d Config 2's synthetic variant): 20 siblings, accepted by the Python
+    interpreter for notes of a depth-20 tree, refused for a wrong sibling at the new levels and for an index >= 2^20."""
+    import spp
+    from oracle import circuit as C
+    path = str(tmp_path / "w20.sppc")
+    n = spp.build_circuit(spp.lib.SPP_CIRCUIT_WITHDRAW_DEPTH20, path)
+    c = C.Circuit(path)
+    assert c.n_constraints == n and (c.n_public - 1, c.n_secret) == (5, 25) and c.domain_log == 14
+    rows = _depth20_rows(3)
+    chal = lambda w: 0x5eed
+    for r in rows:
+        assert C.first_unsatisfied(c, C.solve(c, r, chal)) == -1
+    bad = list(rows[1]); bad[10 + 19] += 1                # the topmost sibling
+    assert C.first_unsatisfied(c, C.solve(c, bad, chal)) >= 0
+    bad = list(rows[1]); bad[9] = 1 << 20
+    assert C.first_unsatisfied(c, C.solve(c, bad, chal)) >= 0
