@@ -245,6 +245,10 @@ def main():
             vkb = open(vkp, "rb").read()
             for i in (0, B - 1):
                 assert spp.verify(vkb, pbytes[388 * i:388 * (i + 1)], wbytes[h.pw_len * i:h.pw_len * (i + 1)]), "proof %d does not verify" % i
+            # ... and every proof of that batch with the batched GPU verifier (spp_verify_batch)
+            all_ok = ctx.verify_batch(vkb, [pbytes[388 * i:388 * (i + 1)] for i in range(B)],
+                                      [wbytes[h.pw_len * i:h.pw_len * (i + 1)] for i in range(B)])
+            assert all(all_ok), "%d proofs of the last timed batch do not verify" % (B - sum(all_ok))
             total_proofs = B * world * steps
             value = total_proofs / elapsed
             sizes = h.msm_sizes()
@@ -274,6 +278,7 @@ def main():
                     "table_bytes": h.table_bytes, "parallelism": "independent proofs x%d" % world,
                     "pk_bcast_ms": round(bcast_ms, 3), "setup_s": round(setup_s, 2), "load_s": round(load_s, 2),
                     "host_buffer_entry_proofs_per_s": round(host_rate, 1),
+                    "last_timed_batch_verified": "all %d proofs accepted by spp_verify_batch (GPU), two of them also by spp_verify (host)" % B,
                     "host_buffer_entry_note": "one spp_prove_batch call with host pointers for 4 batches' worth of proofs: PCIe copies included, chunks pipelined inside libspp"},
                 "stage_ms_per_step": {k: round(v / steps, 3) for k, v in zip(
                     ["solve+commit", "matrix_eval", "ntt_qap", "msm_g1", "msm_g2_side_stream_join", "assemble", "total"], acc["stage"])},
