@@ -104,7 +104,7 @@ size_t msm_table_elems(uint32_t N, uint32_t c);
 // lane g -> (slice g / P, proof g % P); partial[S][P]
 template <class F>
 void launch_msm_accumulate(hipStream_t st, const Affine<F>* table, const uint32_t* rows, const Fr* scalars, XYZZ<F>* partial, uint32_t N,
-                           uint32_t P, uint32_t c, uint32_t S);
+                           uint32_t P, uint32_t c, uint32_t S, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // out[p] = sum_s partial[s][p]   (S = 0: out[p] = infinity)
 template <class F>
 void launch_msm_reduce(hipStream_t st, const XYZZ<F>* partial, XYZZ<F>* out, uint32_t P, uint32_t S);

@@ -13,6 +13,7 @@
 // uniform, and windows in which every proof has a zero digit (bits, bytes, small signed noise -- most of
 // the audit witness) are skipped for the whole wave.  Work is split over S slices of the base range to
 // fill 256 CUs; a second kernel folds the S partial sums per proof through LDS.
+#include <hip/hip_ext.h>
 #include "kernels.hpp"
 #include "f29.hpp"
 
@@ -232,22 +233,29 @@ __global__ void __launch_bounds__(64) k_msm_reduce(const XYZZ<F>* __restrict__ p
   if (t == 0) out[p] = sh[0];
 }
 
+// ev_start / ev_stop (optional): receive the dispatch's own start and stop timestamps (hipExtLaunchKernelGGL), i.e. the
+// kernel's duration as a profiler reports it -- an event pair recorded around the launch would also count the time the
+// launch waits for kernels of the other proving stream.
 template <class F>
 void launch_msm_accumulate(hipStream_t st, const Affine<F>* table, const uint32_t* rows, const Fr* scalars, XYZZ<F>* partial, uint32_t N,
-                           uint32_t P, uint32_t c, uint32_t S) {
-  if (N == 0 || S == 0) return;
+                           uint32_t P, uint32_t c, uint32_t S, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  if (N == 0 || S == 0) {
+    if (ev_start) hipEventRecord(ev_start, st);
+    if (ev_stop) hipEventRecord(ev_stop, st);
+    return;
+  }
   uint64_t lanes = (uint64_t)S * P;
-  hipLaunchKernelGGL(k_msm_fixed<F>, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, st, table, rows, scalars, partial, N, P, c,
-                     msm_windows(c), S);
+  hipExtLaunchKernelGGL(k_msm_fixed<F>, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, st, ev_start, ev_stop, 0, table, rows, scalars,
+                        partial, N, P, c, msm_windows(c), S);
 }
 template <class F>
 void launch_msm_reduce(hipStream_t st, const XYZZ<F>* partial, XYZZ<F>* out, uint32_t P, uint32_t S) {
   hipLaunchKernelGGL(k_msm_reduce<F>, dim3(P), dim3(64), 0, st, partial, out, P, S);
 }
 template void launch_msm_accumulate<Fq>(hipStream_t, const Affine<Fq>*, const uint32_t*, const Fr*, XYZZ<Fq>*, uint32_t, uint32_t, uint32_t,
-                                        uint32_t);
+                                        uint32_t, hipEvent_t, hipEvent_t);
 template void launch_msm_accumulate<Fq2>(hipStream_t, const Affine<Fq2>*, const uint32_t*, const Fr*, XYZZ<Fq2>*, uint32_t, uint32_t,
-                                         uint32_t, uint32_t);
+                                         uint32_t, uint32_t, hipEvent_t, hipEvent_t);
 template void launch_msm_reduce<Fq>(hipStream_t, const XYZZ<Fq>*, XYZZ<Fq>*, uint32_t, uint32_t);
 template void launch_msm_reduce<Fq2>(hipStream_t, const XYZZ<Fq2>*, XYZZ<Fq2>*, uint32_t, uint32_t);
 

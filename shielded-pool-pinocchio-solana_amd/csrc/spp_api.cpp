@@ -841,9 +841,8 @@ static void run_msm(spp_circuit* c, Workspace& w, const MsmSet<F>& s, MsmBuf<F>&
   while (S > 1 && (size_t)S * P > b.partial_cap) S--;  // never exceed the allocated partial buffer
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
   if (timed && w.msm_ev_used < w.msm_ev.size()) ev = &w.msm_ev[w.msm_ev_used++];
-  if (ev) hipEventRecord(ev->first, st);
-  launch_msm_accumulate<F>(st, s.table, s.rows, scal, b.partial, s.N, P, s.c, S);
-  if (ev) hipEventRecord(ev->second, st);
+  // the event pair receives the dispatch's own start/stop timestamps (what rocprofv3 reports as the kernel's duration)
+  launch_msm_accumulate<F>(st, s.table, s.rows, scal, b.partial, s.N, P, s.c, S, ev ? ev->first : nullptr, ev ? ev->second : nullptr);
   launch_msm_reduce<F>(st, b.partial, b.out, P, s.N ? S : 0);
 }
 
