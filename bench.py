@@ -25,42 +25,6 @@ sys.path.insert(0, os.path.join(ROOT, "shielded-pool-pinocchio-solana_amd"))
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def synth_withdraw_rows(count, seed=2, depth=16):
-    """Synthetic, valid withdraw inputs: `count` notes inserted in one depth-16 (or depth-20) Poseidon tree
-    (client/merkle.ts semantics).  Built with the oracle's pure-Python hashes -- bounded to 8 distinct notes,
-    repeated to fill the batch (the GPU work is data-independent)."""
-    import random
-    from oracle import hashes as H
-    rng = random.Random(seed)
-    distinct = min(count, 8)
-    tree = H.MerkleTree(depth)
-    notes = []
-    for _ in range(distinct):
-        sk = rng.randrange(1, 1 << 128)
-        owner = H.fixed_base_scalar_mul(sk)
-        amount = rng.randrange(1, 1 << 40)
-        rnd = rng.randrange(1 << 250)
-        idx = tree.insert(H.poseidon_hash4(owner[0], owner[1], amount, rnd))
-        notes.append((sk, owner, amount, rnd, idx))
-    root = tree.root()
-    rows = []
-    for sk, owner, amount, rnd, idx in notes:
-        rows.append([root, H.poseidon_hash2(sk, idx), rng.randrange(1, 1 << 240), amount, H.poseidon_hash2(owner[0], owner[1]),
-                     sk, owner[0], owner[1], rnd, idx] + tree.proof(idx))
-    return [rows[i % distinct] for i in range(count)]
-
-
-def synth_audit_rows(count, seed=3):
-    import random
-    from oracle import rlwe
-    pk = json.load(open(os.path.join(ROOT, "tests", "golden", "rlwe_pk.json")))
-    distinct = min(count, 4)
-    rows = []
-    for i in range(distinct):
-        rows.append(rlwe.audit_input_vector(rlwe.audit_inputs(pk["a"], pk["b"], 12345 + i, random.Random(1000 + i + seed))))
-    return [rows[i % distinct] for i in range(count)]
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,12 +98,16 @@ def main():
         h = ctx.load_circuit(sppc, pkp, args.window)
         load_s = time.time() - t0
 
-        # ---- synthetic batch, resident in HBM ----
+        # ---- synthetic batch of DISTINCT rows (spp/workload.py, built with the HIP witness-input kernels), resident in HBM ----
+        from spp import workload
         if circuit == "withdraw_depth20":
-            rows = synth_withdraw_rows(B, seed=20, depth=20)
+            rows_b = workload.withdraw_rows(ctx, B, seed=20 + rank, depth=20)
+        elif circuit.startswith("withdraw"):
+            rows_b = workload.withdraw_rows(ctx, B, seed=2 + rank)
         else:
-            rows = synth_withdraw_rows(B) if circuit.startswith("withdraw") else synth_audit_rows(B)
-        inp = torch.frombuffer(bytearray(b"".join(int(v).to_bytes(32, "big") for r in rows for v in r)), dtype=torch.uint8).to(dev)
+            rows_b = workload.audit_rows(ctx, pk["a"], pk["b"], B, first=rank * B)
+        rows = [workload.row_ints(rows_b, h.n_inputs, i) for i in range(min(B, 256))]   # sample for the CPU baseline leg
+        inp = torch.frombuffer(bytearray(rows_b), dtype=torch.uint8).to(dev)
         rs_bytes = b"".join((1000003 * (rank * B + i) + 17).to_bytes(32, "big") + (998244353 * (rank * B + i) + 29).to_bytes(32, "big")
                             for i in range(B))
         rs = torch.frombuffer(bytearray(rs_bytes), dtype=torch.uint8).to(dev)

@@ -176,6 +176,15 @@ int spp_audit_inputs_batch_device(spp_ctx* ctx, const void* d_pk_a, const void* 
 int spp_verify_batch(spp_ctx* ctx, const uint8_t* vk, size_t vk_len, size_t count, const uint8_t* proofs, const uint8_t* pws, size_t pw_len,
                      int32_t* ok, float* kernel_ms);
 
+/* prod_k e(P_k, Q_k) == 1 for 1..4 caller-supplied pairs (G1 64 B, G2 128 B, gnark raw uncompressed), computed on the GPU
+ * with the device pairing code of spp_verify_batch (curve + subgroup checks included; *ok = 0 when a point is invalid).
+ * No call site in the reference: it exists so that the only gnark-made curve data the reference holds -- its verifying keys
+ * noir_circuit/target/shielded_pool_verifier.vk and audit_circuit/target/rlwe_audit.vk -- can be put through the device
+ * pairing path (e(beta1, G2) == e(G1, beta2) etc.; tests/test_vk_pins.py).  The _host variant runs the single-proof host
+ * pairing of spp_verify instead and needs no GPU. */
+int spp_pairing_check(spp_ctx* ctx, uint32_t n_pairs, const uint8_t* g1s, const uint8_t* g2s, int* ok);
+int spp_pairing_check_host(uint32_t n_pairs, const uint8_t* g1s, const uint8_t* g2s, int* ok);
+
 /* ---- auditor side (scripts/rlwe_decrypt.py:61-132, demo-frontend/app/lib/shamir.ts:97-169) ---- */
 /* Shamir reconstruction at 0 over BN254 Fr for n coefficients from t shares: xs[t] share indices, ys = t * n * 32 B
  * (share-major, big-endian). secret_be (optional): n * 32 B; sk_mod_q (optional): the centred value reduced mod q

@@ -790,10 +790,9 @@ int orc_setup(const char* circuit_path, const uint8_t seed[32], const char* pk_p
   cls[c->challenge_wire] = 1;
   for (uint32_t i = 0; i < c->n_committed; i++) cls[c->committed[i]] = 2;
 
-  fe gi, di, sigi;
+  fe gi, di;
   fe_inv(&gi, &gamma, &FR);
   fe_inv(&di, &delta, &FR);
-  fe_inv(&sigi, &sigma, &FR);
 
   fb1_t T1;
   fb2_t T2;
@@ -860,7 +859,7 @@ int orc_setup(const char* circuit_path, const uint8_t seed[32], const char* pk_p
   fb2_mul(&t2, &T2, &delta); g2j_to_affine(&delta2, &t2);
   fb2_mul(&t2, &T2, &rho); g2j_to_affine(&pedG, &t2);
   fe nrs;
-  fe_mul(&nrs, &rho, &sigi, &FR);
+  fe_mul(&nrs, &rho, &sigma, &FR);   /* GSigmaNeg = -sigma * G (gnark-crypto pedersen.Setup) */
   fe_neg(&nrs, &nrs, &FR);
   fb2_mul(&t2, &T2, &nrs); g2j_to_affine(&pedGS, &t2);
 
@@ -1052,6 +1051,39 @@ int orc_prove(void* ctx, const uint8_t* inputs, const uint8_t r32[32], const uin
     for (uint32_t i = 0; i < np; i++) fe_to_be(pw + 12 + 32 * (size_t)i, &w[1 + i], &FR);
   }
   free(w); free(a); free(b); free(cv);
+  return 0;
+}
+
+/* Solver + satisfaction check only (no proof), `count` input rows in parallel: first_unsat[i] = -1 when row i satisfies every
+ * constraint, else the index of the first unsatisfied one (-2: the solver itself failed).  Used by the soundness sweeps in
+ * tests/test_circuit_soundness.py (every input +-1 must be refused). */
+int orc_check_many(void* ctx, int count, const uint8_t* inputs, int32_t* first_unsat) {
+  orc_ctx* x = (orc_ctx*)ctx;
+  circuit_t* c = x->c;
+  uint32_t W = c->n_wires, nin = c->n_public - 1 + c->n_secret;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int i = 0; i < count; i++) {
+    fe* w = (fe*)calloc(W, sizeof(fe));
+    w[0] = FR.one;
+    for (uint32_t k = 0; k < nin; k++) fe_from_be(&w[1 + k], inputs + ((size_t)i * nin + k) * 32, &FR);
+    chal_ctx_t cc;
+    cc.x = x;
+    int32_t res = -1;
+    if (solve(c, w, challenge_cb, &cc) != 0) {
+      res = -2;
+    } else {
+      for (uint32_t k = 0; k < c->n_constraints; k++) {
+        fe a, b, cv, t;
+        row_dot(&a, c, &c->A, k, w);
+        row_dot(&b, c, &c->B, k, w);
+        row_dot(&cv, c, &c->C, k, w);
+        fe_mul(&t, &a, &b, &FR);
+        if (!fe_eq(&t, &cv)) { res = (int32_t)k; break; }
+      }
+    }
+    first_unsat[i] = res;
+    free(w);
+  }
   return 0;
 }
 

@@ -88,6 +88,12 @@ def verify(vk_bytes, proof_bytes, pw_bytes):
     pub = parse_public_witness(pw_bytes)
     if len(pub) + 2 != len(vk["K"]):
         return False
+    # canonical encodings only: gnark's readers refuse a public word >= r or a coordinate >= q instead of reducing it
+    if any(v >= B.R for v in pub):
+        return False
+    for off in list(range(0, 256, 32)) + list(range(260, 388, 32)):
+        if int.from_bytes(proof_bytes[off:off + 32], "big") >= B.P:
+            return False
     for p in (pr["Ar"], pr["Krs"], pr["commitment"], pr["pok"]):
         if not B.g1_is_on_curve(p):
             return False
@@ -96,7 +102,8 @@ def verify(vk_bytes, proof_bytes, pw_bytes):
     if _g2_times_r(pr["Bs"]) is not None:      # order-r subgroup (the twist has a large cofactor)
         return False
     # Pedersen proof of knowledge of the commitment
-    if not B.pairing_product_is_one([(pr["commitment"], vk["ped_G"]), (pr["pok"], vk["ped_GSigmaNeg"])]):
+    # gnark-crypto pedersen.VerifyingKey.Verify: e(commitment, GSigmaNeg) * e(pok, G) == 1
+    if not B.pairing_product_is_one([(pr["commitment"], vk["ped_GSigmaNeg"]), (pr["pok"], vk["ped_G"])]):
         return False
     challenge = B.hash_to_fr(B.g1_to_bytes(pr["commitment"]), B.DST_COMMITMENT, 1)[0]
     ksum = vk["K"][0]

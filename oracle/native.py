@@ -26,6 +26,7 @@ def lib():
             getattr(L, f).argtypes = [ctypes.c_void_p]
             getattr(L, f).restype = ctypes.c_uint32
         L.orc_prove_many.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_check_many.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_void_p]
         L.orc_msm_g1.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p]
         L.orc_ntt.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int]
         _LIB = L
@@ -75,6 +76,15 @@ def prove_many(prover, rows, rs):
     pws = ctypes.create_string_buffer(pwl * count)
     rc = lib().orc_prove_many(prover.h, count, buf, rsb, ctypes.cast(proofs, ctypes.c_void_p), ctypes.cast(pws, ctypes.c_void_p))
     return rc, [proofs.raw[388 * i:388 * (i + 1)] for i in range(count)], [pws.raw[pwl * i:pwl * (i + 1)] for i in range(count)]
+
+
+def check_many(prover, rows):
+    """Solver + satisfaction check for many input rows (parallel): list of -1 (satisfied) / first unsatisfied constraint / -2."""
+    count = len(rows)
+    buf = b"".join(int(v).to_bytes(32, "big") for row in rows for v in row)
+    out = (ctypes.c_int32 * count)()
+    lib().orc_check_many(prover.h, count, buf, ctypes.cast(out, ctypes.c_void_p))
+    return list(out)
 
 
 def set_threads(n):

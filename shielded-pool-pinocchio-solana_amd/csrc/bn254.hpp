@@ -333,6 +333,19 @@ struct Fp {
   }
 };
 
+// true iff the 32-byte big-endian integer is below the modulus: the canonical encodings gnark's readers accept
+// (a public-witness word >= r, or a point coordinate >= q, is refused, never reduced -- otherwise v and v + r would be two
+// byte strings for one nullifier)
+template <class P>
+SPP_HD bool be_is_canonical(const uint8_t in[32]) {
+  for (int i = 0; i < 8; i++) {
+    const uint32_t w = ((uint32_t)in[4 * i] << 24) | ((uint32_t)in[4 * i + 1] << 16) | ((uint32_t)in[4 * i + 2] << 8) | in[4 * i + 3];
+    const uint32_t m = P::MOD(7 - i);
+    if (w < m) return true;
+    if (w > m) return false;
+  }
+  return false;   // equal to the modulus
+}
 using Fr = Fp<FrParams>;
 using Fq = Fp<FqParams>;
 

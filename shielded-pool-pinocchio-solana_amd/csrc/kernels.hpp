@@ -86,6 +86,8 @@ void launch_count8(hipStream_t st, DevCircuit dc, Fr* W, uint32_t* counters, uin
 struct VerifyKeyDev;
 void launch_verify(hipStream_t st, const VerifyKeyDev* vk, const uint8_t* proofs, const uint8_t* pws, uint32_t pw_len, uint32_t count,
                    int32_t* ok);
+struct PairingCheckDev;
+void launch_pairing_check(hipStream_t st, const PairingCheckDev* a, int32_t* ok);
 void launch_spmv_check(hipStream_t st, DevCircuit dc, const Fr* W, Fr* abc, uint32_t n, uint32_t P, uint32_t* status);
 
 // ---- NTT / QAP ----

@@ -261,6 +261,16 @@ struct VerifyKeyDev {
   uint32_t nk;
 };
 
+// arguments of k_pairing_check (spp_pairing_check): up to 4 pairs; tab[k-1] = line table of Q[k] for k >= 1
+struct PairingCheckDev {
+  PairingFastConsts pc;
+  Fq2 twist_b;
+  const LineStep* tab[3];
+  G1Affine P[4];
+  G2Affine Q[4];
+  uint32_t n;
+};
+
 // MSB-first double-and-add as a small rolled loop around out-of-line point operations.  Codegen hazard found on gfx950
 // (ROCm 7.2, tests/micro/verify_probe.hip): with dbl/madd over Fq2 inlined, this LEAF function grew to ~100 KB, its
 // loop back-edges needed long branches, and the branch relaxation scavenged s[30:31] -- the live return address -- for

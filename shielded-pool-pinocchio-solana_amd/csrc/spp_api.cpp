@@ -1128,9 +1128,9 @@ extern "C" int spp_setup(spp_ctx* ctx, const char* circuit_path, const uint8_t s
   for (uint32_t j = 0; j < circ.n_public; j++) cls[j] = 1;
   cls[circ.challenge_wire] = 1;
   for (uint32_t w : circ.committed) cls[w] = 2;
-  const Fr gi = gamma.inv(), di = delta.inv(), sigi = sigma.inv();
+  const Fr gi = gamma.inv(), di = delta.inv();
   // scalar vectors, one fixed-base multiplication each:
-  //   G1: [A(W) | B1(W) | K(W) | S(W) | Z(n-1) | alpha beta delta]    G2: [B2(W) | beta gamma delta rho -rho/sigma]
+  //   G1: [A(W) | B1(W) | K(W) | S(W) | Z(n-1) | alpha beta delta]    G2: [B2(W) | beta gamma delta rho -rho*sigma]
   std::vector<Fr> s1, s2;
   s1.reserve((size_t)4 * W + n + 3);
   for (uint32_t j = 0; j < W; j++) s1.push_back(aw[j]);
@@ -1149,7 +1149,7 @@ extern "C" int spp_setup(spp_ctx* ctx, const char* circuit_path, const uint8_t s
   }
   s1.push_back(alpha); s1.push_back(beta); s1.push_back(delta);
   for (uint32_t j = 0; j < W; j++) s2.push_back(bw[j]);
-  s2.push_back(beta); s2.push_back(gamma); s2.push_back(delta); s2.push_back(rho); s2.push_back((rho * sigi).neg());
+  s2.push_back(beta); s2.push_back(gamma); s2.push_back(delta); s2.push_back(rho); s2.push_back((rho * sigma).neg());
 
   // generator tables (c = 8) and the batched fixed-base multiplications on the GPU
   const uint32_t cb = 8, Wn = msm_windows(cb), E = 1u << (cb - 1);
@@ -1704,12 +1704,19 @@ extern "C" int spp_verify(const uint8_t* vk, size_t vk_len, const uint8_t* proof
   if (be32(pw + 4) != 0 || be32(pw + 8) != npub || pw_len != 12 + 32 * (size_t)npub || npub + 2 != nk)
     return fail(SPP_ERR_FORMAT, "public witness does not match the verifying key");
   if (be32(proof + 256) != 1) return fail(SPP_ERR_FORMAT, "proof must carry exactly one commitment");
+  // canonical encodings only (gnark's readers refuse a coordinate >= q or a witness word >= r; reducing them would make
+  // v and v + r two byte strings for the same nullifier)
+  for (size_t o : {0, 32, 64, 96, 128, 160, 192, 224, 260, 292, 324, 356})
+    if (!be_is_canonical<FqParams>(proof + o)) return SPP_OK;   // ok = 0
+  for (uint32_t i = 0; i < npub; i++)
+    if (!be_is_canonical<FrParams>(pw + 12 + 32 * (size_t)i)) return SPP_OK;
   G1Affine Ar = g1_from_raw(proof), Krs = g1_from_raw(proof + 192), Cm = g1_from_raw(proof + 260), Pok = g1_from_raw(proof + 324);
   G2Affine Bs = g2_from_raw(proof + 64);
   if (!g1_on_curve(Ar) || !g1_on_curve(Krs) || !g1_on_curve(Cm) || !g1_on_curve(Pok) || !g2_on_curve(Bs)) return SPP_OK;   // ok = 0
   if (!g2_in_subgroup(Bs)) return SPP_OK;   // the twist has a large cofactor: Bs must lie in the order-r subgroup
-  // Pedersen proof of knowledge of the commitment
-  if (!pairing_product_is_one({{Cm, pedG}, {Pok, pedGS}})) return SPP_OK;
+  // Pedersen proof of knowledge of the commitment, gnark-crypto's current convention (VerifyingKey{G, GSigmaNeg = -sigma G},
+  // PoK = sum v_i * sigma Basis_i):  e(Cm, GSigmaNeg) * e(PoK, G) == 1
+  if (!pairing_product_is_one({{Cm, pedGS}, {Pok, pedG}})) return SPP_OK;
   // challenge = hash_to_field(commitment, "bsb22-commitment")
   const char* dst = "bsb22-commitment";
   uint8_t u[48];
@@ -1792,6 +1799,70 @@ extern "C" int spp_verify_batch(spp_ctx* ctx, const uint8_t* vk, size_t vk_len, 
   hipEventDestroy(e1);
   if (kernel_ms) *kernel_ms = ms;
   HIP_TRY(hipMemcpy(ok, dok.p, count * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return SPP_OK;
+}
+
+// prod_k e(P_k, Q_k) == 1 on the GPU with the device pairing code of the batched verifier (k_pairing_check).
+extern "C" int spp_pairing_check(spp_ctx* ctx, uint32_t n_pairs, const uint8_t* g1s, const uint8_t* g2s, int* ok) {
+  if (!ctx || !g1s || !g2s || !ok) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  *ok = 0;
+  if (n_pairs < 1 || n_pairs > 4) return fail(SPP_ERR_BAD_INPUT, "1 to 4 pairs");
+  for (uint32_t k = 0; k < n_pairs; k++) {
+    for (int o = 0; o < 64; o += 32)
+      if (!be_is_canonical<FqParams>(g1s + 64 * k + o)) return fail(SPP_ERR_FORMAT, "G1 coordinate not below q");
+    for (int o = 0; o < 128; o += 32)
+      if (!be_is_canonical<FqParams>(g2s + 128 * k + o)) return fail(SPP_ERR_FORMAT, "G2 coordinate not below q");
+  }
+  if (!pairing_fast_consts_consistent()) return fail(SPP_ERR_HIP, "internal: Frobenius constants are not two-term");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  PairingCheckDev h;
+  h.pc = make_pairing_fast_consts();
+  h.twist_b = twist_b();
+  h.n = n_pairs;
+  DevBuf dtab[3], darg, dok;
+  std::vector<LineStep> tabs_host[3];
+  for (uint32_t k = 0; k < 4; k++) {
+    h.P[k] = k < n_pairs ? g1_from_raw(g1s + 64 * k) : G1Affine::infinity();
+    h.Q[k] = k < n_pairs ? g2_from_raw(g2s + 128 * k) : G2Affine::infinity();
+  }
+  for (uint32_t k = 1; k < 4; k++) {
+    h.tab[k - 1] = nullptr;
+    if (k >= n_pairs) continue;
+    if (h.Q[k].is_inf() || !g2_on_curve(h.Q[k])) return SPP_OK;   // ok = 0 (a line table needs a point of the twist)
+    tabs_host[k - 1] = build_line_table(h.Q[k]);
+    UP(dtab[k - 1], tabs_host[k - 1].data(), tabs_host[k - 1].size() * sizeof(LineStep));
+    h.tab[k - 1] = dtab[k - 1].as<LineStep>();
+  }
+  UP(darg, &h, sizeof h);
+  HIP_TRY(dok.alloc(sizeof(int32_t)));
+  launch_pairing_check(st, darg.as<PairingCheckDev>(), dok.as<int32_t>());
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipGetLastError());
+  int32_t res = 0;
+  HIP_TRY(hipMemcpy(&res, dok.p, sizeof res, hipMemcpyDeviceToHost));
+  *ok = res;
+  return SPP_OK;
+}
+
+// same product on the host with the single-proof pairing (pairing.hpp): needs no GPU
+extern "C" int spp_pairing_check_host(uint32_t n_pairs, const uint8_t* g1s, const uint8_t* g2s, int* ok) {
+  if (!g1s || !g2s || !ok) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  *ok = 0;
+  if (n_pairs < 1 || n_pairs > 8) return fail(SPP_ERR_BAD_INPUT, "1 to 8 pairs");
+  std::vector<std::pair<G1Affine, G2Affine>> pairs;
+  for (uint32_t k = 0; k < n_pairs; k++) {
+    for (int o = 0; o < 64; o += 32)
+      if (!be_is_canonical<FqParams>(g1s + 64 * k + o)) return fail(SPP_ERR_FORMAT, "G1 coordinate not below q");
+    for (int o = 0; o < 128; o += 32)
+      if (!be_is_canonical<FqParams>(g2s + 128 * k + o)) return fail(SPP_ERR_FORMAT, "G2 coordinate not below q");
+    G1Affine P = g1_from_raw(g1s + 64 * k);
+    G2Affine Q = g2_from_raw(g2s + 128 * k);
+    if (!g1_on_curve(P) || Q.is_inf() || !g2_on_curve(Q) || !g2_in_subgroup(Q)) return SPP_OK;
+    pairs.push_back({P, Q});
+  }
+  *ok = pairing_product_is_one(pairs) ? 1 : 0;
   return SPP_OK;
 }
 

@@ -2,8 +2,8 @@
 // (kernels_verify.hip, one lane per proof) and of the host check in tests/host/pairing_check.cpp.
 // Same decisions, in the same order, as the host verifier spp_verify (csrc/spp_api.cpp), i.e. `sunspot verify`
 // (noir_circuit/prove_linux.sh:86-87) and the byte layout withdraw.rs:13-16,63-90 fixes:
-//   1. format: commitment count == 1, witness header; G1 points on the curve, Bs on the twist AND in the order-r subgroup;
-//   2. Pedersen proof of knowledge:  e(Cm, G) * e(PoK, GSigmaNeg) == 1;
+//   1. format: commitment count == 1, witness header; every coordinate < q and every public word < r (canonical encodings); G1 points on the curve, Bs on the twist AND in the order-r subgroup;
+//   2. Pedersen proof of knowledge (gnark-crypto pedersen.VerifyingKey.Verify):  e(Cm, GSigmaNeg) * e(PoK, G) == 1;
 //   3. challenge = fr.Hash(Cm, "bsb22-commitment");  ksum = K0 + sum pub_i K_i + challenge K_last + Cm;
 //   4. e(Ar, Bs) * e(-alpha, beta) * e(-ksum, gamma) * e(-Krs, delta) == 1.
 #pragma once
@@ -56,6 +56,13 @@ SPP_HDN bool verify_one(const VerifyKeyDev& vk, const uint8_t* proof, const uint
   const uint32_t npub = vk.nk - 2;
   if (be32_at(proof + 256) != 1) return false;
   if (be32_at(pw) != npub || be32_at(pw + 4) != 0 || be32_at(pw + 8) != npub) return false;
+  // canonical encodings only: coordinates < q, public words < r (never reduced)
+  for (int o = 0; o < 388; o += 32) {
+    if (o == 256) o = 260;
+    if (!be_is_canonical<FqParams>(proof + o)) return false;
+  }
+  for (uint32_t k = 0; k < npub; k++)
+    if (!be_is_canonical<FrParams>(pw + 12 + 32 * k)) return false;
   const G1Affine Ar = g1_from_raw_hd(proof), Krs = g1_from_raw_hd(proof + 192), Cm = g1_from_raw_hd(proof + 260),
                  Pok = g1_from_raw_hd(proof + 324);
   const G2Affine Bs = g2_from_raw_hd(proof + 64);
@@ -63,7 +70,7 @@ SPP_HDN bool verify_one(const VerifyKeyDev& vk, const uint8_t* proof, const uint
   if (!g2_on_curve_hd(Bs, vk.twist_b) || !g2_in_subgroup(Bs)) return false;
   {   // 2. proof of knowledge of the commitment
     const LineStep* tabs[2] = {vk.tab[2], vk.tab[3]};
-    const G1Affine Ps[2] = {Cm, Pok};
+    const G1Affine Ps[2] = {Pok, Cm};   // tab[2] = G, tab[3] = GSigmaNeg: e(PoK, G) * e(Cm, GSigmaNeg)
     const F12 f = miller_multi(2, tabs, Ps, false, G1Affine::infinity(), G2Affine::infinity(), f12_one(pc), pc);
     if (!final_exp_is_one(f, pc)) return false;
   }

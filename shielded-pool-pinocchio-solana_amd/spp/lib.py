@@ -61,6 +61,8 @@ def load_library():
     L.spp_prove_withdraw.argtypes = [vp, ctypes.POINTER(WithdrawInputs), cp, vp, vp]
     L.spp_verify.argtypes = [cp, sz, cp, sz, cp, sz, ctypes.POINTER(i32)]
     L.spp_verify_batch.argtypes = [vp, cp, sz, sz, cp, cp, sz, vp, ctypes.POINTER(ctypes.c_float)]
+    L.spp_pairing_check.argtypes = [vp, u32, cp, cp, ctypes.POINTER(i32)]
+    L.spp_pairing_check_host.argtypes = [u32, cp, cp, ctypes.POINTER(i32)]
     L.spp_debug_witness.argtypes = [vp, vp, sz]
     L.spp_rlwe_witness_batch.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.spp_rlwe_witness_batch_device.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp]

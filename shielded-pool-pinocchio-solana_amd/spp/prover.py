@@ -22,6 +22,14 @@ def verify(vk_bytes, proof_bytes, pw_bytes):
     return bool(ok.value)
 
 
+def pairing_check_host(pairs):
+    """prod e(P, Q) == 1 with the product's host pairing (no GPU). pairs: list of (g1 64 B, g2 128 B)."""
+    L = load_library()
+    ok = ctypes.c_int(0)
+    check(L.spp_pairing_check_host(len(pairs), b"".join(p for p, _ in pairs), b"".join(q for _, q in pairs), ctypes.byref(ok)))
+    return bool(ok.value)
+
+
 class Context:
     def __init__(self, device=0):
         self.L = load_library()
@@ -62,6 +70,12 @@ class Context:
         sc = b"".join(int(s).to_bytes(32, "big") for s in scalars)
         check(self.L.spp_msm_g1_pippenger(self.h, bases_bytes, sc, len(scalars), ctypes.cast(out, ctypes.c_void_p)))
         return out.raw
+
+    def pairing_check(self, pairs):
+        """prod e(P, Q) == 1 on the GPU with the batched verifier's device pairing code (spp_pairing_check)."""
+        ok = ctypes.c_int(0)
+        check(self.L.spp_pairing_check(self.h, len(pairs), b"".join(p for p, _ in pairs), b"".join(q for _, q in pairs), ctypes.byref(ok)))
+        return bool(ok.value)
 
     def verify_batch(self, vk, proofs, pws, want_ms=False):
         """`sunspot verify` for many proofs against one key, on the GPU (spp_verify_batch). proofs / pws: lists of bytes.

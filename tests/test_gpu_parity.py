@@ -178,6 +178,79 @@ def test_full_size_batch_is_consistent_with_small_batches(withdraw_handle, withd
         assert rc == 0 and proofs[i] == proof and pws[i] == pw
 
 
+def test_full_batch_of_distinct_withdraw_rows(ctx, withdraw_handle, withdraw_artifacts):
+    """A bench-size batch in which EVERY row is a different note (4096 identities, one tree, every index / sibling path
+    different: spp/workload.py, the shape of client/payroll-demo.ts:199-352): all proofs produced, a sample byte-identical
+    to the oracle's proofs of the same rows, every proof accepted by the batched verifier, inputs agree with the oracle's
+    hashes (pinned by client/prover-params.toml)."""
+    from spp import workload
+    from oracle import native, groth16, hashes as H
+    B_ = 4096
+    rows_b = workload.withdraw_rows(ctx, B_, seed=5)
+    n_in = withdraw_handle.n_inputs
+    assert len(rows_b) == B_ * n_in * 32
+    assert len({rows_b[32 * n_in * i + 32:32 * n_in * (i + 1)] for i in range(B_)}) == B_          # all rows distinct (root aside)
+    import ctypes
+    rs = b"".join((7919 * i + 3).to_bytes(32, "big") + (104729 * i + 5).to_bytes(32, "big") for i in range(B_))
+    proofs = ctypes.create_string_buffer(388 * B_)
+    pws = ctypes.create_string_buffer(withdraw_handle.pw_len * B_)
+    status = (ctypes.c_int32 * B_)()
+    rc = withdraw_handle.L.spp_prove_batch(withdraw_handle.h, B_, rows_b, rs, ctypes.cast(proofs, ctypes.c_void_p),
+                                           ctypes.cast(pws, ctypes.c_void_p), ctypes.cast(status, ctypes.c_void_p))
+    assert rc == 0 and not any(status)
+    pl = [proofs.raw[388 * i:388 * (i + 1)] for i in range(B_)]
+    wl = [pws.raw[withdraw_handle.pw_len * i:withdraw_handle.pw_len * (i + 1)] for i in range(B_)]
+    assert len(set(pl)) == B_
+    orc = native.Prover(withdraw_artifacts["sppc"], withdraw_artifacts["pk"])
+    rng = random.Random(99)
+    sample = [0, 1, 63, 64, 2047, 2048, B_ - 1] + [rng.randrange(B_) for _ in range(9)]
+    for i in sample:
+        row = workload.row_ints(rows_b, n_in, i)
+        rc, proof, pw = orc.prove(row, 7919 * i + 3, 104729 * i + 5)
+        assert rc == 0 and pl[i] == proof and wl[i] == pw, i
+        # the row itself is what the reference's client code would compute (oracle/hashes.py restates client/merkle.ts)
+        sk, ox, oy, amount, rnd, idx = row[5], row[6], row[7], row[3], row[8], row[9]
+        assert H.fixed_base_scalar_mul(sk) == (ox, oy) and idx == i
+        assert row[1] == H.poseidon_hash2(sk, idx) and row[4] == H.poseidon_hash2(ox, oy)
+        assert H.compute_merkle_root(H.poseidon_hash4(ox, oy, amount, rnd), idx, row[10:26]) == row[0]
+    vk = open(withdraw_artifacts["vk"], "rb").read()
+    assert all(ctx.verify_batch(vk, pl, wl))
+    assert groth16.verify(vk, pl[sample[-1]], wl[sample[-1]])
+
+
+def test_batch_of_distinct_audit_rows(ctx, audit_artifacts, rlwe_pk):
+    """SURVEY 8d Config 3's rows (sk_i = 12345 + i, Random(1000 + i)) built on the GPU, every row distinct: 256 proofs, a
+    sample byte-identical to the oracle's, all accepted by the batched verifier; the rows equal the oracle's restatement
+    of scripts/generate_audit.py:468-641 for the same parameters."""
+    from spp import workload
+    from oracle import native, rlwe
+    B_ = 256
+    rows_b = workload.audit_rows(ctx, rlwe_pk["a"], rlwe_pk["b"], B_, first=40)
+    h = ctx.load_circuit(audit_artifacts["sppc"], audit_artifacts["pk"], 6)
+    try:
+        import ctypes
+        rs = b"".join((31 * i + 3).to_bytes(32, "big") + (37 * i + 5).to_bytes(32, "big") for i in range(B_))
+        proofs = ctypes.create_string_buffer(388 * B_)
+        pws = ctypes.create_string_buffer(h.pw_len * B_)
+        status = (ctypes.c_int32 * B_)()
+        rc = h.L.spp_prove_batch(h.h, B_, rows_b, rs, ctypes.cast(proofs, ctypes.c_void_p), ctypes.cast(pws, ctypes.c_void_p),
+                                 ctypes.cast(status, ctypes.c_void_p))
+        assert rc == 0 and not any(status)
+        n_in = h.n_inputs
+    finally:
+        h.close()
+    pl = [proofs.raw[388 * i:388 * (i + 1)] for i in range(B_)]
+    wl = [pws.raw[76 * i:76 * (i + 1)] for i in range(B_)]
+    assert len(set(pl)) == B_
+    orc = native.Prover(audit_artifacts["sppc"], audit_artifacts["pk"])
+    for i in (0, 77, B_ - 1):
+        row = workload.row_ints(rows_b, n_in, i)
+        assert row == rlwe.audit_input_vector(rlwe.audit_inputs(rlwe_pk["a"], rlwe_pk["b"], 12345 + 40 + i, random.Random(1000 + 40 + i)))
+        rc, proof, pw = orc.prove(row, 31 * i + 3, 37 * i + 5)
+        assert rc == 0 and pl[i] == proof and wl[i] == pw, i
+    assert all(ctx.verify_batch(open(audit_artifacts["vk"], "rb").read(), pl, wl))
+
+
 def test_batched_verifier_matches_the_single_proof_verifiers(ctx, withdraw_handle, withdraw_artifacts, audit_artifacts, withdraw_kat, rlwe_pk):
     """spp_verify_batch on real proofs of both circuits: accepts what the oracle and the host verifier
     accept, and rejects -- lane by lane -- a flipped byte in each proof element, a wrong public input, a proof checked
@@ -201,8 +274,27 @@ def test_batched_verifier_matches_the_single_proof_verifiers(ctx, withdraw_handl
     cases.append((proofs[1], flip(pws[1], 3))); expect.append(False)           # header
     cases.append((proofs[2], pws[3])); expect.append(False)                    # another statement's inputs
     cases.append((bytes(388), pws[0])); expect.append(False)                   # refused row
+    # aliased encodings: v + r in a public word (same nullifier, other bytes), coordinate + q in the proof -- refused, not reduced
+    from oracle import bn254 as B
+    def add_at(b, off, m):
+        x = bytearray(b); v = int.from_bytes(x[off:off + 32], "big") + m
+        if v >= 1 << 256:
+            return None
+        x[off:off + 32] = v.to_bytes(32, "big"); return bytes(x)
+    n_alias = 0
+    for k in range(5):
+        a = add_at(pws[4], 12 + 32 * k, B.R)
+        if a is not None:
+            cases.append((proofs[4], a)); expect.append(False); n_alias += 1
+    for off in (0, 32, 64, 192, 260, 324):
+        a = add_at(proofs[4], off, B.P)
+        if a is not None:
+            cases.append((a, pws[4])); expect.append(False); n_alias += 1
+    assert n_alias >= 6
     got = ctx.verify_batch(vk, [c[0] for c in cases], [c[1] for c in cases])
     assert got == expect
+    for (pr, pw), e in list(zip(cases, expect))[-n_alias:]:
+        assert groth16.verify(vk, pr, pw) == e and spp.verify(vk, pr, pw) == e
     for (pr, pw), e in list(zip(cases, expect))[:8]:
         assert groth16.verify(vk, pr, pw) == e and spp.verify(vk, pr, pw) == e
     assert ctx.verify_batch(vk, [], []) == []

@@ -200,6 +200,27 @@ def test_product_verifier_agrees_with_oracle(withdraw_artifacts, audit_artifacts
             assert got is False
         pw2 = bytearray(pw); pw2[-1] ^= 1
         assert not spp.verify(vk, proof, bytes(pw2))
+        # aliased public inputs: v + r encodes the same field element in other bytes (for a nullifier: a second spend of
+        # the same note); gnark's witness reader refuses such words, and so must every verifier here -- for EVERY input
+        from oracle import bn254 as B
+        npub = (len(pw) - 12) // 32
+        tried = 0
+        for k in range(npub):
+            v = int.from_bytes(pw[12 + 32 * k:44 + 32 * k], "big")
+            for mult in (1, 2, 3, 4, 5):
+                if v + mult * B.R < 1 << 256:
+                    al = pw[:12 + 32 * k] + (v + mult * B.R).to_bytes(32, "big") + pw[44 + 32 * k:]
+                    assert not spp.verify(vk, proof, al), (k, mult)
+                    assert not groth16.verify(vk, proof, al), (k, mult)
+                    tried += 1
+        assert tried >= 5 * npub - 2
+        # aliased point coordinates (x + q): refused, the proof is not malleable through its encoding
+        for off in list(range(0, 256, 32)) + list(range(260, 388, 32)):
+            v = int.from_bytes(proof[off:off + 32], "big") + B.P
+            if v < 1 << 256:
+                al = proof[:off] + v.to_bytes(32, "big") + proof[off + 32:]
+                assert not spp.verify(vk, al, pw), off
+                assert not groth16.verify(vk, al, pw), off
     with pytest.raises(spp.SppError):
         spp.verify(cases[0][0], cases[0][1][:100], cases[0][2])      # truncated proof
     assert not spp.verify(cases[0][0], cases[1][1], cases[0][2])     # proof of the other circuit
@@ -326,30 +347,43 @@ def test_verifiers_reject_bs_outside_the_subgroup(withdraw_artifacts, withdraw_k
     assert not spp.verify(vk, forged, pw)
 
 
-def test_no_return_address_clobber_in_verifier_device_code(tmp_path):
+def test_no_return_address_clobber_in_device_code(tmp_path):
     """Codegen hazard met on gfx950 / ROCm 7.2: in a large LEAF device function whose loop back-edges
     need long branches, the branch relaxation used s[30:31] -- the live return address -- for s_getpc/s_setpc, and the
-    function never returned.  The verifier's out-of-line functions are structured to avoid it; this scans the gfx950
-    assembly of kernels_verify.hip for the pattern."""
+    function never returned.  Out-of-line device functions are structured to avoid it; this scans the gfx950 assembly of
+    EVERY translation unit of libspp (all .hip files, and the .cpp files the Makefile compiles with -x hip) for the pattern."""
+    import glob
     import shutil
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
     csrc = os.path.join(ROOT, "shielded-pool-pinocchio-solana_amd", "csrc")
-    asm = str(tmp_path / "kv.s")
-    subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-S", "--cuda-device-only",
-                    "-o", asm, os.path.join(csrc, "kernels_verify.hip")], check=True, stderr=subprocess.DEVNULL)
-    txt = open(asm).read()
-    kernels = set(re.findall(r"\.amdhsa_kernel (\S+)", txt))
-    offenders = []
-    for name in re.findall(r"^(_Z\w+):", txt, re.M):
-        if name in kernels:
-            continue
-        body = txt.split(name + ":", 1)[1]
-        body = body[:body.find(".Lfunc_end")]
-        if re.search(r"s_getpc_b64 s\[30:31\]", body):
-            offenders.append(name)
+    units = sorted(glob.glob(os.path.join(csrc, "*.hip"))) + [os.path.join(csrc, f) for f in ("spp_api.cpp", "circuit.cpp", "circuit_audit.cpp")]
+    assert len(units) >= 10
+
+    def scan(src):
+        asm = str(tmp_path / (os.path.basename(src) + ".s"))
+        subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-x", "hip", "-S",
+                        "--cuda-device-only", "-o", asm, src], check=True, stderr=subprocess.DEVNULL)
+        txt = open(asm).read()
+        kernels = set(re.findall(r"\.amdhsa_kernel (\S+)", txt))
+        bad, n_funcs = [], 0
+        for name in re.findall(r"^(_Z\w+):", txt, re.M):
+            if name in kernels:
+                continue
+            n_funcs += 1
+            body = txt.split(name + ":", 1)[1]
+            body = body[:body.find(".Lfunc_end")]
+            if re.search(r"s_getpc_b64 s\[30:31\]", body):
+                bad.append(os.path.basename(src) + ":" + name)
+        return bad, n_funcs
+
+    with ThreadPoolExecutor(4) as ex:
+        results = list(ex.map(scan, units))
+    offenders = [o for bad, _ in results for o in bad]
     assert not offenders, offenders
+    assert sum(n for _, n in results) > 0      # the scan saw out-of-line device functions at all
 
 
 def test_committed_bench_line_follows_the_contract():

@@ -19,14 +19,25 @@ def test_prover_params_kat(withdraw_kat):
 
 
 def test_noir_unit_test_vector():
-    """noir_circuit/src/main.nr:84-130: sk 12345, index 0, zero siblings -- main() must be satisfiable."""
+    """noir_circuit/src/main.nr:84-130: sk 12345, amount 1000000, randomness 67890, index 0, ZERO siblings.  The hash-level
+    part (the values main() recomputes and asserts equal, :60-78); the same vector goes through the product's R1CS in
+    tests/test_circuit_soundness.py::test_noir_unit_test_vector_through_the_circuit."""
     from oracle import hashes as H
     owner = H.fixed_base_scalar_mul(12345)
+    assert H.identity_keypair(12345)[1] == owner
     cm = H.poseidon_hash4(owner[0], owner[1], 1000000, 67890)
-    assert H.compute_merkle_root(cm, 0, [0] * 16) == H.compute_merkle_root(cm, 0, [0] * 16)
-    t = H.MerkleTree()
-    t.insert(cm)
-    assert t.proof(0) == H.default_hashes()[:16]
+    # compute_merkle_root with index 0: sixteen left-child steps H2(current, 0) (main.nr:11-29)
+    cur = cm
+    for _ in range(16):
+        cur = H.poseidon_hash2(cur, 0)
+    assert H.compute_merkle_root(cm, 0, [0] * 16) == cur
+    # index bit set -> the sibling goes left (main.nr:19-23)
+    nxt = H.poseidon_hash2(7, cm)
+    for _ in range(15):
+        nxt = H.poseidon_hash2(nxt, 0)
+    assert H.compute_merkle_root(cm, 1, [7] + [0] * 15) == nxt
+    pv = H.withdraw_public_values(12345, 1000000, 67890, 0, [0] * 16)
+    assert pv["root"] == cur and pv["nullifier"] == H.poseidon_hash2(12345, 0) and pv["wa_commitment"] == H.poseidon_hash2(*owner)
 
 
 def test_poseidon2_kat_and_constants():
