@@ -1,19 +1,32 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Groth16 proofs/sec on MI355X (BASELINE.json metric).
+"""Headline benchmark: Groth16 proofs/sec on MI355X (BASELINE.json metric; headline circuit = audit_circuit, the one the
+target names).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--circuit withdraw|audit] [--window C]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--circuit audit|withdraw] [--batch B] [--mode weak|strong] [--total T]
 
-One "step" = one batch of B independent proofs of the circuit, inputs already resident in HBM, proofs
-(388 B) and public witnesses written to HBM.  N > 1: one process per GPU (torch.distributed / RCCL); the
-proving key is produced on rank 0 and broadcast once over RCCL (timed separately, excluded from the metric);
-each rank then proves its own B proofs with no data-path collective ("weak" scaling: B per GPU fixed).
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (k_msm_fixed<G1>) against HBM peak with
-live HIP-event timings; `cpu_baseline` times the oracle's C/OpenMP prover on a bounded sample of the same
-workload on this host (reported baseline, not the target).
+One "step" = one batch of independent proofs, every row a DIFFERENT witness (spp/workload.py: audit rows sk_i = 12345 + i,
+Random(1000 + i) as SURVEY 8d Config 3; withdraw rows = distinct notes of one tree), inputs already resident in HBM, proofs
+(388 B) and public witnesses written to HBM.
+
+N > 1: one process per GPU.  Launched by the driver through torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the
+environment) or, when WORLD_SIZE is absent, by this script itself: `python bench.py --gpus N` starts N rank processes
+BEFORE anything touches the GPU and waits for them.  Rank 0 runs the trusted setup, the proving key is broadcast once over
+RCCL (timed as pk_bcast_ms, outside the metric), and every rank proves its own rows with no data-path collective.
+  --mode weak   (default) B proofs per GPU per step                      -> "scaling": "weak"
+  --mode strong a fixed total of T proofs per step (default 1024 = BASELINE.json configs[2]) cut into contiguous blocks with
+                spp.multi.shard_range                                    -> "scaling": "strong"
+Rank 0 prints ONE JSON line.  At N = 1 the line also carries the withdraw circuit (own shape, the reference's R1CS size, the
+depth-20 variant), the RLWE witness kernel on 2^16 instances (configs[3]) and the 2^24-point Pippenger MSM (configs[4]).
+`roofline` prices the dominant kernel (k_msm_fixed<G1>) against the HBM peak from a serialised probe (three steps on one
+stream after the timed region, durations from the dispatches' own timestamps) -- in the pipelined timed region the same
+dispatches share the chip with the other batch and last longer; both figures are in the line.  `cpu_baseline` times the
+oracle's C/OpenMP prover on a bounded sample of the same rows on this host (reported baseline, not the target).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -23,59 +36,223 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "shielded-pool-pinocchio-solana_amd"))
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SETS = ["CB", "A", "B1", "K", "Z", "CS", "B2(G2)"]          # launch order of spp_msm_kernel_ms
+INFO_ORDER = ["A", "B1", "K", "Z", "CB", "CS", "B2(G2)"]    # order of spp_circuit_msm_sizes / _windows
+WORKLOADS = {"withdraw": "noir_circuit withdraw (Poseidon Merkle depth 16 + Grumpkin)",
+             "withdraw_refshape": "noir_circuit withdraw padded with ballast multiplications to the reference's gnark R1CS size (12 452 constraints, 2^14)",
+             "withdraw_depth20": "withdraw statement over a depth-20 Poseidon tree (synthetic variant; the reference is depth 16)",
+             "audit": "audit_circuit (RLWE, const-PK; scripts/generate_audit.py:246-465)"}
+DEFAULT_BATCH = {"withdraw": 4096, "audit": 2048, "withdraw_refshape": 2048, "withdraw_depth20": 2048}
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)    # SURVEY 8d timing rule: warm-up 3, >= 10 iterations or >= 2 s
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=0, help="proofs per GPU per step in weak mode (0 = 2048 audit / 4096 withdraw)")
+    ap.add_argument("--circuit", default=os.environ.get("SPP_BENCH_CIRCUIT", "audit"), choices=["withdraw", "audit"])
+    ap.add_argument("--mode", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--total", type=int, default=1024, help="strong mode: proofs per step over all GPUs (BASELINE.json configs[2]: 1024)")
+    ap.add_argument("--window", type=int, default=int(os.environ.get("SPP_WINDOW", "0")), help="MSM window bits; 0 = auto (largest tables within the HBM budget)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline circuit only (profiling runs)")
+    ap.add_argument("--no-single", action="store_true", help="skip the single-proof latency leg (keeps profiler per-kernel averages clean)")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N rank processes (fresh interpreters, nothing in this process has
+    touched the GPU), one device each, and return the worst exit code.  Rank 0 inherits stdout and prints the JSON line."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
+
+
+def dry_run(args, rank, world, dist, coll_dev):
+    """SPP_BENCH_DRYRUN=1 (CPU tests of the launcher / rendezvous / sharding logic, tests/test_multi_gloo.py): everything
+    bench.py does around the GPU work -- key broadcast, shard ranges, barrier-bracketed timing with MAX over ranks, one JSON
+    line from rank 0 -- with the proving itself replaced by a sleep."""
+    import torch
+    from spp.multi import broadcast_blob, shard_range
+    blob = bytes(range(256)) * 64
+    if dist:
+        blob = broadcast_blob(dist, blob if rank == 0 else None, 0, coll_dev)
+    assert len(blob) == 256 * 64 and blob[:4] == bytes([0, 1, 2, 3])
+    per = args.batch or 8
+    lo, hi = shard_range(args.total, rank, world) if args.mode == "strong" else (rank * per, (rank + 1) * per)
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.0005 * (hi - lo))
+    if dist:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    total = hi - lo
+    if dist:
+        t = torch.tensor([el], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+        c = torch.tensor([hi - lo], dtype=torch.int64, device=coll_dev)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        total = int(c.item())
+    if rank == 0:
+        print(json.dumps({"metric": "Groth16 proofs/sec", "value": round(total * args.steps / el, 3), "unit": "proofs/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True,
+                          "scaling": args.mode, "vs_baseline": None, "dtype": "u32x8 (254-bit Montgomery integers)", "data": "synthetic",
+                          "config": {"workload": "DRY RUN (no GPU work): launcher / rendezvous / sharding rehearsal", "dry_run": True,
+                                     "proofs_per_step_all_gpus": total, "parallelism": "independent proofs x%d" % world}}), flush=True)
+
+
+def rlwe_leg(ctx, dev, pk, iters=10):
+    """BASELINE.json configs[3]: RLWE negacyclic witness generation, 2^16 instances on one GPU (scripts/generate_audit.py:507-584)."""
+    import ctypes
+    import numpy as np
+    import torch
+    import spp
+    from oracle import native
+    cnt = 1 << 16
+    g = torch.Generator(device="cpu").manual_seed(4)
+    a = torch.tensor(pk["a"], dtype=torch.int32, device=dev)
+    b = torch.tensor(pk["b"], dtype=torch.int32, device=dev)
+    r = torch.randint(-3, 4, (cnt, 1024), generator=g, dtype=torch.int8).to(dev)
+    e1 = torch.randint(-3, 4, (cnt, 64), generator=g, dtype=torch.int8).to(dev)
+    e2 = torch.randint(-3, 4, (cnt, 1024), generator=g, dtype=torch.int8).to(dev)
+    msg = torch.randint(0, 256, (cnt, 64), generator=g, dtype=torch.uint8).to(dev)
+    c0 = torch.zeros((cnt, 64), dtype=torch.int32, device=dev)
+    c1 = torch.zeros((cnt, 1024), dtype=torch.int32, device=dev)
+    k0 = torch.zeros((cnt, 64), dtype=torch.int32, device=dev)
+    k1 = torch.zeros((cnt, 1024), dtype=torch.int32, device=dev)
+    packed = torch.zeros((cnt, 157 * 32), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    L = ctx.L
+
+    def run():
+        spp.lib.check(L.spp_rlwe_witness_batch_device(ctx.h, a.data_ptr(), b.data_ptr(), cnt, r.data_ptr(), e1.data_ptr(), e2.data_ptr(),
+                                                      msg.data_ptr(), c0.data_ptr(), c1.data_ptr(), k0.data_ptr(), k1.data_ptr(), packed.data_ptr()))
+    for _ in range(3):
+        run()
+    spp.lib.check(L.spp_ctx_sync(ctx.h))
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        run()
+    spp.lib.check(L.spp_ctx_sync(ctx.h))
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    # parity spot check of the timed outputs against the oracle (C, scalar) + its time as the CPU figure
+    sel = [0, 1, 4097, cnt - 1]
+    an, bn = np.array(pk["a"], dtype=np.uint32), np.array(pk["b"], dtype=np.uint32)
+    p = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+    t0 = time.perf_counter()
+    for i in sel:
+        oc0 = np.zeros(64, dtype=np.uint32); oc1 = np.zeros(1024, dtype=np.uint32)
+        ok0 = np.zeros(64, dtype=np.int64); ok1 = np.zeros(1024, dtype=np.int64)
+        native.lib().orc_rlwe_witness(p(an), p(bn), p(r[i].cpu().numpy().astype(np.int32)), p(e1[i].cpu().numpy().astype(np.int32)),
+                                      p(e2[i].cpu().numpy().astype(np.int32)), p(msg[i].cpu().numpy().astype(np.uint32)), p(oc0), p(oc1), p(ok0), p(ok1))
+        assert (c1[i].cpu().numpy().astype(np.uint32) == oc1).all() and (k1[i].cpu().numpy() == ok1).all(), "RLWE instance %d differs from the oracle" % i
+        assert (c0[i].cpu().numpy().astype(np.uint32) == oc0).all() and (k0[i].cpu().numpy() == ok0).all()
+    cpu_s = (time.perf_counter() - t0) / len(sel)
+    alg = 21504.0 * cnt + 8192     # SURVEY 8d: 21 504 B per instance + the public key once
+    return {"metric": "RLWE witness instances/sec", "value": round(cnt / (ms * 1e-3), 1), "unit": "instances/s", "iters": iters,
+            "config": {"workload": "2^16 RLWE instances: two negacyclic n=1024 products, 1088 exact quotients, 7x32-bit packing (BASELINE configs[3])"},
+            "ms_per_batch": round(ms, 3),
+            "roofline": {"bound": "hbm", "kernel": "k_rlwe_witness", "achieved": round(alg / (ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None, "alg_bytes_per_launch": int(alg)},
+            "cpu_baseline": {"value": round(1.0 / cpu_s, 2), "unit": "instances/s", "cores": 1, "kind": "port",
+                             "sample": "%d instances, oracle C schoolbook (the reference's CPython path: 1.4 instances/s/core, BASELINE.md)" % len(sel)}}
+
+
+def pippenger_leg(ctx, iters=10):
+    """BASELINE.json configs[4]: 2^24-point BN254 G1 MSM over general bases (Pippenger), uniform and witness-like scalars."""
+    import ctypes
+    import random
+    from oracle import native, bn254 as B
+    n = 1 << 24
+    res, ms, ms_bucket = ctx.msm_g1_pippenger_bench(n, seed=5, iters=iters)
+    res_w, ms_w, ms_bucket_w = ctx.msm_g1_pippenger_bench(n, seed=5, iters=iters, small_permille=700)
+    # linearity (size-independent property at the full size): MSM(3 * scalars) == 3 * MSM(scalars)
+    res3, _, _ = ctx.msm_g1_pippenger_bench(n, seed=5, scale=3, iters=1)
+    assert B.g1_to_bytes(B.g1_mul(B.g1_from_bytes(res), 3)) == res3, "Pippenger 2^24 is not linear in the scalars"
+    alg = 96.0 * n
+    ns = 1 << 16
+    rng = random.Random(1)
+    bases = B.g1_to_bytes(B.g1_mul(B.G1_GEN, 12345)) * ns
+    sc = b"".join(rng.randrange(B.R).to_bytes(32, "big") for _ in range(ns))
+    out = ctypes.create_string_buffer(64)
+    t0 = time.perf_counter()
+    native.lib().orc_msm_g1(bases, sc, ns, ctypes.cast(out, ctypes.c_void_p))
+    cpu_s = time.perf_counter() - t0
+    return {"metric": "G1 MSM points/sec (Pippenger, general bases)", "value": round(n / (ms * 1e-3), 1), "unit": "points/s", "iters": iters,
+            "config": {"workload": "2^24-point BN254 G1 MSM, uniform 253-bit scalars, bases k_i*G generated on device (BASELINE configs[4])"},
+            "ms_per_msm": round(ms, 3),
+            "witness_like_70pct_small": {"ms_per_msm": round(ms_w, 3), "points_per_s": round(n / (ms_w * 1e-3), 1), "bucket_kernel_ms": round(ms_bucket_w, 3)},
+            "roofline": {"bound": "hbm", "kernel": "whole MSM (sort + bucket accumulation + reduction)", "achieved": round(alg / (ms * 1e-3) / 1e9, 3),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+                         "alg_bytes_per_launch": int(alg), "bucket_kernel_ms": round(ms_bucket, 3)},
+            "cpu_baseline": {"value": round(ns / cpu_s, 1), "unit": "points/s", "cores": native.max_threads(), "kind": "port",
+                             "sample": "2^16-point MSM, oracle C Pippenger"}}
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)    # SURVEY 8d timing rule: warm-up 3, >= 10 iterations or >= 2 s
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=0, help="proofs per GPU per step (0 = 4096 for withdraw, 2048 for audit)")
-    ap.add_argument("--circuit", default=os.environ.get("SPP_BENCH_CIRCUIT", "withdraw"), choices=["withdraw", "audit"])
-    ap.add_argument("--window", type=int, default=int(os.environ.get("SPP_WINDOW", "0")), help="MSM window bits; 0 = auto (largest tables within the HBM budget)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the second circuit")
-    ap.add_argument("--no-single", action="store_true", help="skip the single-proof latency leg (keeps profiler per-kernel averages clean)")
-    ap.add_argument("--no-refshape", action="store_true", help="skip the withdraw circuit padded to the reference's R1CS size")
-    args = ap.parse_args()
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))        # nothing above this line imports torch or touches HIP
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1) and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     dist = None
-    # rehearsal switches (one-GPU boxes): SPP_BENCH_BACKEND=gloo runs the collectives on CPU tensors and
+    # rehearsal switches (one-GPU boxes / CPU tests): SPP_BENCH_BACKEND=gloo runs the collectives on CPU tensors and
     # SPP_FORCE_DEVICE=k puts every rank on GPU k; the real multi-GPU run uses neither (nccl = RCCL, one GPU per rank)
     backend = os.environ.get("SPP_BENCH_BACKEND", "nccl")
+    dry = os.environ.get("SPP_BENCH_DRYRUN") == "1"
     if "SPP_FORCE_DEVICE" in os.environ:
         local_rank = int(os.environ["SPP_FORCE_DEVICE"])
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        torch.cuda.set_device(local_rank)
         if backend == "nccl":
+            torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
+    coll_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
+    if dry:
+        dry_run(args, rank, world, dist, coll_dev)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     dev = torch.device("cuda", local_rank)
-    coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     import spp
+    from spp import workload
+    from spp.multi import broadcast_blob, shard_range
     from oracle import native
+    rlwe_pk = json.load(open(os.path.join(ROOT, "tests", "golden", "rlwe_pk.json")))
 
-    def run_circuit(circuit, B, steps, warmup, want_cpu):
-        """Returns the result dict for one circuit (rank 0) or None (other ranks)."""
+    def run_circuit(circuit, B, steps, warmup, want_cpu, strong_total=0):
+        """One circuit: setup, load, distinct rows, timed steps, checks.  Returns the result dict on rank 0, None elsewhere.
+        strong_total > 0: this rank proves rows shard_range(strong_total, rank, world) of the fixed batch."""
         tmp = tempfile.mkdtemp(prefix="spp_bench_%d_" % rank)
         sppc, pkp, vkp = (os.path.join(tmp, "c." + e) for e in ("sppc", "pk", "vk"))
-        if circuit == "withdraw":
-            spp.build_circuit(1, sppc)
-        elif circuit == "withdraw_refshape":
-            spp.build_circuit(3, sppc)       # same statement, padded to the reference's gnark R1CS size (12 452 constraints, 2^14)
-        elif circuit == "withdraw_depth20":
-            spp.build_circuit(4, sppc)       # SURVEY 8d Config 2's synthetic variant: a depth-20 tree (the reference is depth 16)
-        else:
-            pk = json.load(open(os.path.join(ROOT, "tests", "golden", "rlwe_pk.json")))
-            spp.build_circuit(2, sppc, aux=list(pk["a"]) + list(pk["b"]))
+        cid = {"withdraw": 1, "audit": 2, "withdraw_refshape": 3, "withdraw_depth20": 4}[circuit]
+        spp.build_circuit(cid, sppc, aux=(list(rlwe_pk["a"]) + list(rlwe_pk["b"])) if cid == 2 else None)
         ctx = spp.Context(local_rank)
         # ---- proving key: GPU setup on rank 0, one RCCL broadcast over xGMI ----
         t0 = time.time()
@@ -84,7 +261,6 @@ def main():
             ctx.setup(sppc, b"\x2a" * 32, pkp, vkp)
         setup_s = time.time() - t0
         if world > 1:
-            from spp.multi import broadcast_blob
             torch.cuda.synchronize()
             dist.barrier()
             tb = time.time()
@@ -93,23 +269,31 @@ def main():
             bcast_ms = (time.time() - tb) * 1e3
             if rank != 0:
                 open(pkp, "wb").write(blob)
+            pk_bytes = len(blob)
             del blob
+        else:
+            pk_bytes = os.path.getsize(pkp)
         t0 = time.time()
         h = ctx.load_circuit(sppc, pkp, args.window)
         load_s = time.time() - t0
 
-        # ---- synthetic batch of DISTINCT rows (spp/workload.py, built with the HIP witness-input kernels), resident in HBM ----
-        from spp import workload
+        # ---- this rank's rows: all distinct, built with the HIP witness-input kernels, resident in HBM ----
+        if strong_total:
+            lo, hi = shard_range(strong_total, rank, world)
+        else:
+            lo, hi = rank * B, (rank + 1) * B
+        B = hi - lo
+        t0 = time.time()
         if circuit == "withdraw_depth20":
             rows_b = workload.withdraw_rows(ctx, B, seed=20 + rank, depth=20)
         elif circuit.startswith("withdraw"):
             rows_b = workload.withdraw_rows(ctx, B, seed=2 + rank)
         else:
-            rows_b = workload.audit_rows(ctx, pk["a"], pk["b"], B, first=rank * B)
-        rows = [workload.row_ints(rows_b, h.n_inputs, i) for i in range(min(B, 256))]   # sample for the CPU baseline leg
+            rows_b = workload.audit_rows(ctx, rlwe_pk["a"], rlwe_pk["b"], B, first=lo)     # proofs lo .. hi-1 of SURVEY 8d Config 3
+        rows_s = time.time() - t0
+        n_distinct = len({rows_b[32 * h.n_inputs * i + 32:32 * h.n_inputs * (i + 1)] for i in range(B)})
         inp = torch.frombuffer(bytearray(rows_b), dtype=torch.uint8).to(dev)
-        rs_bytes = b"".join((1000003 * (rank * B + i) + 17).to_bytes(32, "big") + (998244353 * (rank * B + i) + 29).to_bytes(32, "big")
-                            for i in range(B))
+        rs_bytes = b"".join((1000003 * (lo + i) + 17).to_bytes(32, "big") + (998244353 * (lo + i) + 29).to_bytes(32, "big") for i in range(B))
         rs = torch.frombuffer(bytearray(rs_bytes), dtype=torch.uint8).to(dev)
         # two output sets: consecutive batches are pipelined on two streams inside libspp
         proofs = [torch.zeros(B * 388, dtype=torch.uint8, device=dev) for _ in range(2)]
@@ -130,62 +314,79 @@ def main():
         if dist is not None:
             dist.barrier()
         t0 = time.perf_counter()
-        acc = {"kern_ms": 0.0, "kern_n": 0, "stage": [0.0] * 7}
+        acc = {"stage": [0.0] * 7, "n": 0, "kern": [0.0] * 7}
 
-        def take(tm):
-            acc["kern_ms"] += tm[7] * tm[8]
-            acc["kern_n"] += int(tm[8])
+        def take(which):
+            tm = h.last_timings(which)
+            km = h.msm_kernel_ms(which)
+            acc["n"] += 1
             for i in range(7):
                 acc["stage"][i] += tm[i]
+                acc["kern"][i] += km[i]
 
         for it in range(steps):
             step()
             if it >= 1:
-                take(h.last_timings(1))   # HIP events of the previous step; the step just enqueued keeps the GPU busy
+                take(1)   # events of the previous step; the step just enqueued keeps the GPU busy
         h.sync()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         elapsed = time.perf_counter() - t0
+        total_proofs = B
         if dist is not None:
             t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
+            cnt = torch.tensor([B], dtype=torch.int64, device=coll_dev)
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+            total_proofs = int(cnt.item())
         assert int(status[0].abs().sum().item()) + int(status[1].abs().sum().item()) == 0, "some synthetic proofs were refused"
-        take(h.last_timings(0))           # events of the last timed step (already complete)
+        take(0)           # events of the last timed step (already complete)
 
-        # the same batch through the host-buffer entry point (spp_prove_batch: H2D of the inputs, D2H of proofs/public
+        if rank != 0:
+            h.close()
+            ctx.close()
+            return None
+
+        # ---- serialised roofline probe: one stream, one batch in flight, so a dispatch's duration is its own ----
+        h.set_serial(True)
+        probe = {"kern": [0.0] * 7, "stage": [0.0] * 7, "n": 0}
+        for _ in range(3):
+            step()
+            h.sync()
+            km, tm = h.msm_kernel_ms(0), h.last_timings(0)
+            probe["n"] += 1
+            for i in range(7):
+                probe["kern"][i] += km[i]
+                probe["stage"][i] += tm[i]
+        h.set_serial(False)
+
+        # the same rows through the host-buffer entry point (spp_prove_batch: H2D of the inputs, D2H of proofs / public
         # witnesses, synchronous): the PCIe-inclusive rate, reported beside `value`, never as `value`
-        host_rate = None
-        if rank == 0:
-            import ctypes
-            HB = 4 * B                       # one call with four batches' worth: libspp cuts it into chunks and pipelines them
-            in_host = bytes(inp.cpu().numpy().tobytes()) * 4
-            rs_host = bytes(rs.cpu().numpy().tobytes()) * 4
-            ph = ctypes.create_string_buffer(388 * HB)
-            wh = ctypes.create_string_buffer(h.pw_len * HB)
-            sh = (ctypes.c_int32 * HB)()
-            args_h = (h.h, HB, in_host, rs_host, ctypes.cast(ph, ctypes.c_void_p), ctypes.cast(wh, ctypes.c_void_p), ctypes.cast(sh, ctypes.c_void_p))
-            assert h.L.spp_prove_batch(*args_h) == 0
-            assert ph.raw[388 * (HB - 1):388 * HB] == ph.raw[388 * (B - 1):388 * B]      # same inputs, same blinding, same bytes
-            th = time.perf_counter()
-            for _ in range(2):
-                assert h.L.spp_prove_batch(*args_h) == 0
-            host_rate = 2 * HB / (time.perf_counter() - th)
+        import ctypes
+        HB = 4 * B                       # one call with four batches' worth: libspp cuts it into chunks and pipelines them
+        in_host, rs_host = rows_b * 4, rs_bytes * 4
+        ph = ctypes.create_string_buffer(388 * HB)
+        wh = ctypes.create_string_buffer(h.pw_len * HB)
+        sh = (ctypes.c_int32 * HB)()
+        args_h = (h.h, HB, in_host, rs_host, ctypes.cast(ph, ctypes.c_void_p), ctypes.cast(wh, ctypes.c_void_p), ctypes.cast(sh, ctypes.c_void_p))
+        assert h.L.spp_prove_batch(*args_h) == 0
+        assert ph.raw[388 * (HB - 1):388 * HB] == ph.raw[388 * (B - 1):388 * B]      # same inputs, same blinding, same bytes
+        th = time.perf_counter()
+        assert h.L.spp_prove_batch(*args_h) == 0
+        host_rate = HB / (time.perf_counter() - th)
+        del in_host, rs_host
 
-        # SURVEY 8d Config 2: ONE withdraw proof from the reference's own inputs (client/prover-params.toml, committed as
-        # tests/golden/withdraw_kat.json), end to end on the device-resident entry point: latency, and proofs/s at batch 1
+        # SURVEY 8d Config 1/2: ONE proof from the reference's own inputs, end to end on the device-resident entry point
         single = None
-        if rank == 0 and circuit in ("withdraw", "audit") and not args.no_single:
+        if circuit in ("withdraw", "audit") and not args.no_single and world == 1:
             if circuit == "withdraw":
                 from oracle import circuit as OC
                 kat_row = OC.withdraw_inputs(json.load(open(os.path.join(ROOT, "tests", "golden", "withdraw_kat.json"))))
                 kat_name = "client/prover-params.toml (tests/golden/withdraw_kat.json)"
-            else:   # SURVEY 8d Config 1: the reference's own run, sk = 12345, Random(999) (scripts/generate_audit.py:469-470)
-                import random
-                from oracle import rlwe
-                pkj = json.load(open(os.path.join(ROOT, "tests", "golden", "rlwe_pk.json")))
-                kat_row = rlwe.audit_input_vector(rlwe.audit_inputs(pkj["a"], pkj["b"], 12345, random.Random(999)))
+            else:   # the reference's own run: sk = 12345, Random(999) (scripts/generate_audit.py:469-470)
+                kat_row = workload.row_ints(workload.audit_rows(ctx, rlwe_pk["a"], rlwe_pk["b"], 1, first=0, seed_base=999), h.n_inputs, 0)
                 kat_name = "scripts/generate_audit.py defaults: sk = 12345, Random(999), demo rlwe_pk.json"
             one_in = torch.frombuffer(bytearray(b"".join(int(v).to_bytes(32, "big") for v in kat_row)), dtype=torch.uint8).to(dev)
             one_rs = torch.frombuffer(bytearray((5).to_bytes(32, "big") + (6).to_bytes(32, "big")), dtype=torch.uint8).to(dev)
@@ -202,116 +403,117 @@ def main():
             assert int(one_st.item()) == 0
             assert spp.verify(open(vkp, "rb").read(), one_pr.cpu().numpy().tobytes(), one_pw.cpu().numpy().tobytes())
             lat = sorted(lat[2:])
-            single = {"inputs": kat_name, "latency_ms_median": round(lat[len(lat) // 2], 3),
-                      "latency_ms_min": round(lat[0], 3), "proofs_per_s_at_batch_1": round(1e3 / lat[len(lat) // 2], 2)}
+            single = {"inputs": kat_name, "latency_ms_median": round(lat[len(lat) // 2], 3), "latency_ms_min": round(lat[0], 3),
+                      "proofs_per_s_at_batch_1": round(1e3 / lat[len(lat) // 2], 2)}
 
-        out = None
-        if rank == 0:
-            # the timed batches produced real proofs: check two of the last step with the product's own pairing verifier
-            last = (step_no[0] - 1) & 1
-            pbytes, wbytes = proofs[last].cpu().numpy().tobytes(), pws[last].cpu().numpy().tobytes()
-            vkb = open(vkp, "rb").read()
-            for i in (0, B - 1):
-                assert spp.verify(vkb, pbytes[388 * i:388 * (i + 1)], wbytes[h.pw_len * i:h.pw_len * (i + 1)]), "proof %d does not verify" % i
-            # ... and every proof of that batch with the batched GPU verifier (spp_verify_batch)
-            all_ok = ctx.verify_batch(vkb, [pbytes[388 * i:388 * (i + 1)] for i in range(B)],
-                                      [wbytes[h.pw_len * i:h.pw_len * (i + 1)] for i in range(B)])
-            assert all(all_ok), "%d proofs of the last timed batch do not verify" % (B - sum(all_ok))
-            total_proofs = B * world * steps
-            value = total_proofs / elapsed
-            sizes = h.msm_sizes()
-            g1_sizes = sizes[:6]
-            # algorithmic bytes of one k_msm_fixed<G1> launch: every base once (64 B) + one 32 B scalar per (base, proof)
-            alg_bytes = sum(64 * n + 32 * n * B for n in g1_sizes) / len(g1_sizes)
-            avg_ms = acc["kern_ms"] / max(acc["kern_n"], 1)
-            achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            traffic = None
-            valu_util = None
-            try:   # PMC pass of the same workload, committed under profiles/ (rocprofv3 --pmc cannot run inside this process)
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_latest.json")))
-                if pmc.get("circuit") == circuit and pmc.get("batch") == B and pmc.get("window_bits") == h.window_bits:
-                    traffic = pmc["k_msm_fixed_g1_hbm_bytes_per_launch"]
-                    valu_util = pmc.get("k_msm_fixed_g1_valu_issue_util_serialised")
-            except Exception:
-                pass
-            out = {
-                "value": round(value, 3), "ms_per_step": round(elapsed / steps * 1e3, 3),
-                "config": {"workload": "%s, batch of %d independent proofs per GPU per step" % (
-                    {"withdraw": "noir_circuit withdraw (Poseidon Merkle depth 16 + Grumpkin)",
-                     "withdraw_refshape": "noir_circuit withdraw padded with ballast multiplications to the reference's gnark R1CS size",
-                     "withdraw_depth20": "withdraw statement over a depth-20 Poseidon tree (synthetic variant; the reference is depth 16)",
-                     "audit": "audit_circuit (RLWE, const-PK)"}[circuit], B),
-                    "circuit": circuit, "n_constraints": h.n_constraints, "n_wires": h.n_wires, "domain": 1 << h.domain_log,
-                    "batch_per_gpu": B, "window_bits": h.window_bits, "msm_windows": dict(zip(["A", "B1", "K", "Z", "CB", "CS", "B2(G2)"], h.msm_windows())), "msm_sizes": dict(zip(["A", "B1", "K", "Z", "CB", "CS", "B2(G2)"], sizes)),
-                    "table_bytes": h.table_bytes, "parallelism": "independent proofs x%d" % world,
-                    "pk_bcast_ms": round(bcast_ms, 3), "setup_s": round(setup_s, 2), "load_s": round(load_s, 2),
-                    "host_buffer_entry_proofs_per_s": round(host_rate, 1),
-                    "last_timed_batch_verified": "all %d proofs accepted by spp_verify_batch (GPU), two of them also by spp_verify (host)" % B,
-                    "host_buffer_entry_note": "one spp_prove_batch call with host pointers for 4 batches' worth of proofs: PCIe copies included, chunks pipelined inside libspp"},
-                "stage_ms_per_step": {k: round(v / steps, 3) for k, v in zip(
-                    ["solve+commit", "matrix_eval", "ntt_qap", "msm_g1", "msm_g2_side_stream_join", "assemble", "total"], acc["stage"])},
-                "roofline": {"bound": "hbm", "kernel": "k_msm_fixed<Fq>", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "alg_bytes_per_launch": int(alg_bytes),
-                             "avg_launch_ms": round(avg_ms, 4), "launches_timed": acc["kern_n"],
-                             "valu_issue_util_pmc": valu_util,   # SQ counters of the serialised run of the same workload (profiles/)
-                             "note": "integer-VALU bound (about 2.3K instructions, 1.5K of them v_mad_u64_u32, per mixed addition); HBM fraction reported as mandated"},
-            }
-            if single is not None:
-                out["single_proof"] = single
-            if want_cpu:
-                orc = native.Prover(sppc, pkp)
-                cores = native.max_threads()
-                # throughput mode: one proof per host thread, rounds of `cores` proofs until ~10 s have elapsed
-                t1 = time.perf_counter()
-                done = 0
-                while done == 0 or (time.perf_counter() - t1 < 10.0 and done < 4096):
-                    batch = [rows[(done + i) % len(rows)] for i in range(cores)]
-                    rc, _, _ = native.prove_many(orc, batch, [(7 + done + i, 11 + done + i) for i in range(cores)])
-                    assert rc == 0
-                    done += cores
-                dt = time.perf_counter() - t1
-                t2 = time.perf_counter()
-                for i in range(3):
-                    assert orc.prove(rows[i % len(rows)], 3 + i, 4 + i)[0] == 0
-                one_ms = (time.perf_counter() - t2) / 3 * 1e3
-                out["cpu_baseline"] = {"value": round(done / dt, 3), "unit": "proofs/s", "cores": cores, "kind": "port",
-                                       "single_proof_latency_ms": round(one_ms, 1),
-                                       "sample": "%d %s proofs, one per host thread, oracle C/OpenMP prover (stands in for the Sunspot "
-                                                 "Go/CPU path, which cannot run here: no Go toolchain, no pk)" % (done, circuit)}
+        # the timed batches produced real proofs: every proof of the last pipelined batch through the batched GPU verifier,
+        # two of them also through the host verifier
+        last = (warmup + steps - 1) & 1
+        pbytes, wbytes = proofs[last].cpu().numpy().tobytes(), pws[last].cpu().numpy().tobytes()
+        vkb = open(vkp, "rb").read()
+        for i in (0, B - 1):
+            assert spp.verify(vkb, pbytes[388 * i:388 * (i + 1)], wbytes[h.pw_len * i:h.pw_len * (i + 1)]), "proof %d does not verify" % i
+        all_ok = ctx.verify_batch(vkb, [pbytes[388 * i:388 * (i + 1)] for i in range(B)], [wbytes[h.pw_len * i:h.pw_len * (i + 1)] for i in range(B)])
+        assert all(all_ok), "%d proofs of the last timed batch do not verify" % (B - sum(all_ok))
+
+        value = total_proofs * steps / elapsed
+        ms_per_step = elapsed / steps * 1e3
+        sizes = dict(zip(INFO_ORDER, h.msm_sizes()))
+        windows = dict(zip(INFO_ORDER, h.msm_windows()))
+        # algorithmic bytes of one k_msm_fixed launch over a batch (64 B per base once + one 32 B scalar per (base, proof))
+        alg = {s: (128 if s.startswith("B2") else 64) * sizes[s] + 32 * sizes[s] * B for s in SETS}
+        g1 = SETS[:6]
+        ser = {s: probe["kern"][i] / probe["n"] for i, s in enumerate(SETS)}
+        pip = {s: acc["kern"][i] / acc["n"] for i, s in enumerate(SETS)}
+        ser_g1_ms = sum(ser[s] for s in g1)
+        alg_g1 = sum(alg[s] for s in g1)
+        achieved = alg_g1 / (ser_g1_ms * 1e-3) / 1e9 if ser_g1_ms > 0 else 0.0
+        traffic, traffic_src, valu_util = None, None, None
+        try:   # PMC passes of the same workload, committed under profiles/ (rocprofv3 --pmc cannot run inside this process)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_latest.json")))
+            if pmc.get("circuit") == circuit and pmc.get("batch") == B and pmc.get("n_distinct_witnesses") == B:
+                traffic = pmc["k_msm_fixed_g1_hbm_bytes_per_launch"]
+                traffic_src = pmc.get("source")
+                valu_util = pmc.get("k_msm_fixed_g1_valu_issue_util_serialised")
+        except Exception:
+            pass
+        out = {
+            "value": round(value, 3), "ms_per_step": round(ms_per_step, 3), "steps": steps, "warmup": warmup,
+            "config": {"workload": "%s, batch of %d independent proofs per GPU per step, every row a distinct witness" % (WORKLOADS[circuit], B),
+                       "circuit": circuit, "n_constraints": h.n_constraints, "n_wires": h.n_wires, "domain": 1 << h.domain_log,
+                       "batch_per_gpu": B, "n_distinct_witnesses": n_distinct, "proofs_per_step_all_gpus": total_proofs,
+                       "msm_windows": windows, "msm_sizes": sizes, "table_bytes": h.table_bytes, "parallelism": "independent proofs x%d" % world,
+                       "pk_bcast_ms": round(bcast_ms, 3), "pk_bytes": pk_bytes, "setup_s": round(setup_s, 2), "load_s": round(load_s, 2),
+                       "rows_synth_s": round(rows_s, 2), "host_buffer_entry_proofs_per_s": round(host_rate, 1),
+                       "last_timed_batch_verified": "all %d proofs accepted by spp_verify_batch (GPU), two of them also by spp_verify (host)" % B,
+                       "host_buffer_entry_note": "one spp_prove_batch call with host pointers for 4 batches' worth of proofs: PCIe copies included, chunks pipelined inside libspp"},
+            "stage_ms_per_step_pipelined": {k: round(v / acc["n"], 3) for k, v in zip(
+                ["solve+commit", "matrix_eval", "ntt_qap", "msm_g1", "msm_g2_side_stream_join", "assemble", "total"], acc["stage"])},
+            "stage_ms_per_step_serialised": {k: round(v / probe["n"], 3) for k, v in zip(
+                ["solve+commit", "matrix_eval", "ntt_qap", "msm_g1", "msm_g2", "assemble", "total"], probe["stage"])},
+            "roofline": {"bound": "hbm", "kernel": "k_msm_fixed<Fq>", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
+                         "alg_bytes_per_launch": int(alg_g1 / 6), "avg_launch_ms": round(ser_g1_ms / 6, 4), "launches_per_step": 6,
+                         "launch_ms_serialised": {s: round(ser[s], 3) for s in SETS},
+                         "launch_ms_in_pipelined_timed_region": {s: round(pip[s], 3) for s in SETS},
+                         "launch_GBps_serialised": {s: round(alg[s] / (ser[s] * 1e-3) / 1e9, 2) if ser[s] > 0 else None for s in SETS},
+                         "timing": "dispatch timestamps (hipExtLaunchKernelGGL events); `achieved` uses the serialised probe (3 steps on one stream after "
+                                   "the timed region): 6 launches x avg_launch_ms <= ms_per_step; in the pipelined region the same dispatches share the chip",
+                         "valu_issue_util_pmc": valu_util,
+                         "note": "integer-VALU bound (about 2.3K instructions, 1.5K of them v_mad_u64_u32, per mixed addition); HBM fraction reported as mandated"},
+        }
+        if single is not None:
+            out["single_proof"] = single
+        if want_cpu:
+            orc = native.Prover(sppc, pkp)
+            cores = native.max_threads()
+            sample = [workload.row_ints(rows_b, h.n_inputs, i) for i in range(min(B, cores))]
+            # throughput mode: one proof per host thread, rounds of `cores` proofs until ~10 s have elapsed
+            t1 = time.perf_counter()
+            done = 0
+            while done == 0 or (time.perf_counter() - t1 < 10.0 and done < 4096):
+                batch = [sample[(done + i) % len(sample)] for i in range(cores)]
+                rc, _, _ = native.prove_many(orc, batch, [(7 + done + i, 11 + done + i) for i in range(cores)])
+                assert rc == 0
+                done += cores
+            dt = time.perf_counter() - t1
+            t2 = time.perf_counter()
+            for i in range(3):
+                assert orc.prove(sample[i % len(sample)], 3 + i, 4 + i)[0] == 0
+            one_ms = (time.perf_counter() - t2) / 3 * 1e3
+            out["cpu_baseline"] = {"value": round(done / dt, 3), "unit": "proofs/s", "cores": cores, "kind": "port",
+                                   "single_proof_latency_ms": round(one_ms, 1),
+                                   "sample": "%d %s proofs (rows of the timed batch), one per host thread, oracle C/OpenMP prover (stands in for the "
+                                             "Sunspot Go/CPU path, which cannot run here: no Go toolchain, no pk)" % (done, circuit)}
         h.close()
         ctx.close()
         del inp, rs, proofs, pws, status
         torch.cuda.empty_cache()
         return out
 
-    default_batch = {"withdraw": 4096, "audit": 2048, "withdraw_refshape": 2048, "withdraw_depth20": 2048}
-    main_res = run_circuit(args.circuit, args.batch or default_batch[args.circuit], args.steps, args.warmup,
-                           not args.no_cpu_baseline and world == 1)   # CPU baseline: rank 0 at N=1 only
-    # the other circuit of BASELINE.json's metric, as a secondary figure (single GPU runs only)
-    other = None
-    if world == 1 and not args.no_secondary:
-        oc = "audit" if args.circuit == "withdraw" else "withdraw"
-        other = run_circuit(oc, default_batch[oc], 3, 1, not args.no_cpu_baseline)
-    # like-for-like size check: the withdraw statement at the reference R1CS's dimensions (12 452 constraints, 2^14)
-    refshape = None
-    if world == 1 and not args.no_refshape and args.circuit == "withdraw":
-        refshape = run_circuit("withdraw_refshape", default_batch["withdraw_refshape"], 3, 1, False)
-    depth20 = None
-    if world == 1 and not args.no_refshape and args.circuit == "withdraw":
-        depth20 = run_circuit("withdraw_depth20", default_batch["withdraw_depth20"], 3, 1, False)
+    strong = args.mode == "strong"
+    B0 = args.batch or DEFAULT_BATCH[args.circuit]
+    main_res = run_circuit(args.circuit, B0, args.steps, args.warmup, not args.no_cpu_baseline and world == 1, args.total if strong else 0)
+    extras = {}
+    if world == 1 and not args.no_extras and not strong:
+        # the other circuits / configs of BASELINE.json, each at >= 10 timed steps, in the same line so that the driver times them
+        want = not args.no_cpu_baseline
+        other = "withdraw" if args.circuit == "audit" else "audit"
+        extras[other + "_circuit"] = run_circuit(other, DEFAULT_BATCH[other], 10, 3, want)
+        extras["withdraw_at_reference_r1cs_size"] = run_circuit("withdraw_refshape", DEFAULT_BATCH["withdraw_refshape"], 10, 3, False)
+        extras["withdraw_depth20_variant"] = run_circuit("withdraw_depth20", DEFAULT_BATCH["withdraw_depth20"], 10, 3, False)
+        ctx = spp.Context(local_rank)
+        extras["rlwe_witness_2p16"] = rlwe_leg(ctx, dev, rlwe_pk)
+        extras["msm_g1_2p24"] = pippenger_leg(ctx)
+        ctx.close()
     if rank == 0:
         line = {"metric": "Groth16 proofs/sec", "value": main_res["value"], "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
-                "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+                "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": args.mode,
                 "vs_baseline": None, "dtype": "u32x8 (254-bit Montgomery integers)", "data": "synthetic"}
-        for k in ("config", "stage_ms_per_step", "roofline", "cpu_baseline", "single_proof"):
+        for k in ("config", "stage_ms_per_step_pipelined", "stage_ms_per_step_serialised", "roofline", "cpu_baseline", "single_proof"):
             if k in main_res:
                 line[k] = main_res[k]
-        if other is not None:
-            line["secondary_" + ("audit" if args.circuit == "withdraw" else "withdraw") + "_circuit"] = other
-        if refshape is not None:
-            line["withdraw_at_reference_r1cs_size"] = refshape
-        if depth20 is not None:
-            line["withdraw_depth20_variant"] = depth20
+        line.update(extras)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -122,6 +122,14 @@ int spp_last_timings(spp_circuit* c, float ms[9]);
  * so reading batch k-1 while batch k runs does not drain the pipeline) */
 int spp_timings(spp_circuit* c, int which, float ms[9]);
 
+/* durations (ms) of the MSM kernel launches of one batch (which: as spp_timings), from the dispatches' own timestamps, in launch
+ * order: commitment, A, B1, K, Z, proof of knowledge (the six k_msm_fixed<G1> launches), then the G2 launch */
+int spp_msm_kernel_ms(spp_circuit* c, int which, float ms[7]);
+/* on = 1: run everything of this circuit on one stream (profiling / roofline probe: a kernel's duration is then its own, not
+ * stretched by the other batch or by the G2 side stream sharing the chip); on = 0: back to the pipelined default.
+ * Synchronises the device. */
+int spp_set_serial(spp_circuit* c, int on);
+
 int spp_prove_withdraw(spp_circuit* c, const spp_withdraw_inputs* in, const uint8_t rs_seed[64], uint8_t proof[SPP_PROOF_LEN],
                        uint8_t pw[SPP_WITHDRAW_PW_LEN]);
 

@@ -160,6 +160,8 @@ struct MsmBuf {
 struct Workspace {
   hipStream_t st = nullptr;
   hipStream_t st2 = nullptr;          // side stream: the G2 MSM only needs the witness, so it runs beside matrix eval / NTT / G1 MSMs
+  hipStream_t own_st = nullptr, own_st2 = nullptr;   // the streams of the pipelined mode (st / st2 point at them unless serialised)
+  std::pair<hipEvent_t, hipEvent_t> g2_ev{nullptr, nullptr};   // dispatch timestamps of the G2 MSM kernel
   hipEvent_t ev_w = nullptr, ev_b2 = nullptr;
   size_t cap = 0, last_P = 0;
   Fr *W = nullptr, *abc = nullptr, *scratch = nullptr;
@@ -737,9 +739,12 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
     // SPP_SERIAL=1 (profiling aid): one stream for everything, so per-stage / per-kernel times are not stretched by
     // the other batch or by the G2 side stream
     const bool serial = getenv("SPP_SERIAL") != nullptr;
-    w.st = ctx->pstream[serial ? 0 : k];
-    if (serial) w.st2 = w.st;
-    else HIP_TRY(hipStreamCreate(&w.st2));
+    w.own_st = ctx->pstream[k];
+    HIP_TRY(hipStreamCreate(&w.own_st2));
+    w.st = serial ? ctx->pstream[0] : w.own_st;
+    w.st2 = serial ? w.st : w.own_st2;
+    HIP_TRY(hipEventCreate(&w.g2_ev.first));
+    HIP_TRY(hipEventCreate(&w.g2_ev.second));
     HIP_TRY(hipEventCreateWithFlags(&w.ev_w, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&w.ev_b2, hipEventDisableTiming));
     for (auto& evt : w.ev) HIP_TRY(hipEventCreate(&evt));
@@ -765,7 +770,9 @@ static void destroy_circuit(spp_circuit* c) {
   hipStreamSynchronize(c->ctx->stream);
   for (auto& w : c->ws) {
     if (w.st) hipStreamSynchronize(w.st);
-    if (w.st2 && w.st2 != w.st) { hipStreamSynchronize(w.st2); hipStreamDestroy(w.st2); }
+    if (w.own_st2) { hipStreamSynchronize(w.own_st2); hipStreamDestroy(w.own_st2); }
+    if (w.g2_ev.first) hipEventDestroy(w.g2_ev.first);
+    if (w.g2_ev.second) hipEventDestroy(w.g2_ev.second);
     if (w.ev_w) hipEventDestroy(w.ev_w);
     if (w.ev_b2) hipEventDestroy(w.ev_b2);
     free_workspace(w);
@@ -834,13 +841,15 @@ static int ensure_workspace(spp_circuit* c, Workspace& w, size_t P) {
 }
 
 template <class F>
-static void run_msm(spp_circuit* c, Workspace& w, const MsmSet<F>& s, MsmBuf<F>& b, uint32_t P, bool timed, hipStream_t st_override = nullptr) {
+static void run_msm(spp_circuit* c, Workspace& w, const MsmSet<F>& s, MsmBuf<F>& b, uint32_t P, bool timed, hipStream_t st_override = nullptr,
+                    std::pair<hipEvent_t, hipEvent_t>* ev_override = nullptr) {
   hipStream_t st = st_override ? st_override : w.st;
   const Fr* scal = s.from_h ? w.abc : w.W;
   uint32_t S = msm_slices(s.N, P);
   while (S > 1 && (size_t)S * P > b.partial_cap) S--;  // never exceed the allocated partial buffer
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
   if (timed && w.msm_ev_used < w.msm_ev.size()) ev = &w.msm_ev[w.msm_ev_used++];
+  if (ev_override) ev = ev_override;
   // the event pair receives the dispatch's own start/stop timestamps (what rocprofv3 reports as the kernel's duration)
   launch_msm_accumulate<F>(st, s.table, s.rows, scal, b.partial, s.N, P, s.c, S, ev ? ev->first : nullptr, ev ? ev->second : nullptr);
   launch_msm_reduce<F>(st, b.partial, b.out, P, s.N ? S : 0);
@@ -872,7 +881,7 @@ static int prove_on_device(spp_circuit* c, Workspace& w, uint32_t P, const uint8
   // the G2 MSM depends on the witness only: start it now on the side stream
   hipEventRecord(w.ev_w, st);
   hipStreamWaitEvent(w.st2, w.ev_w, 0);
-  run_msm(c, w, c->B2, w.B2, P, false, w.st2);
+  run_msm(c, w, c->B2, w.B2, P, false, w.st2, &w.g2_ev);
   hipEventRecord(w.ev_b2, w.st2);
   // 2. constraint evaluations + satisfaction check
   launch_spmv_check(st, c->dc, w.W, w.abc, n, P, d_status);
@@ -953,6 +962,34 @@ extern "C" int spp_timings(spp_circuit* c, int which, float ms[9]) {
   }
   ms[7] = w.msm_ev_used ? sum / (float)w.msm_ev_used : 0.f;
   ms[8] = (float)w.msm_ev_used;
+  return SPP_OK;
+}
+
+// per-launch durations of the MSM kernels of one batch, in launch order: commitment (CB), A, B1, K, Z, PoK (CS), then the G2 set
+extern "C" int spp_msm_kernel_ms(spp_circuit* c, int which, float ms[7]) {
+  if (!c || !ms) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  HIP_TRY(hipSetDevice(c->ctx->device));
+  Workspace& w = c->ws[which ? c->last_ws ^ 1 : c->last_ws];
+  if (w.cap == 0) return fail(SPP_ERR_BAD_INPUT, "no such batch");
+  HIP_TRY(hipStreamSynchronize(w.st));
+  HIP_TRY(hipStreamSynchronize(w.st2));
+  for (int i = 0; i < 7; i++) ms[i] = 0.f;
+  for (size_t i = 0; i < w.msm_ev_used && i < 6; i++) HIP_TRY(hipEventElapsedTime(&ms[i], w.msm_ev[i].first, w.msm_ev[i].second));
+  if (c->B2.N) HIP_TRY(hipEventElapsedTime(&ms[6], w.g2_ev.first, w.g2_ev.second));
+  return SPP_OK;
+}
+// on = 1: both batch workspaces and the G2 MSM run on ONE stream (kernel durations are then not stretched by another stream
+// sharing the chip: what a roofline figure needs); on = 0: the pipelined default.  Drains the device first.
+extern "C" int spp_set_serial(spp_circuit* c, int on) {
+  if (!c) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  std::lock_guard<std::mutex> lk(c->ctx->mu);
+  HIP_TRY(hipSetDevice(c->ctx->device));
+  HIP_TRY(hipDeviceSynchronize());
+  for (int k = 0; k < 2; k++) {
+    Workspace& w = c->ws[k];
+    w.st = on ? c->ws[0].own_st : w.own_st;
+    w.st2 = on ? w.st : w.own_st2;
+  }
   return SPP_OK;
 }
 

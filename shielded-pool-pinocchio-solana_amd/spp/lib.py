@@ -58,6 +58,8 @@ def load_library():
     L.spp_sync.argtypes = [vp]
     L.spp_last_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     L.spp_timings.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_float)]
+    L.spp_msm_kernel_ms.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_float)]
+    L.spp_set_serial.argtypes = [vp, i32]
     L.spp_prove_withdraw.argtypes = [vp, ctypes.POINTER(WithdrawInputs), cp, vp, vp]
     L.spp_verify.argtypes = [cp, sz, cp, sz, cp, sz, ctypes.POINTER(i32)]
     L.spp_verify_batch.argtypes = [vp, cp, sz, sz, cp, cp, sz, vp, ctypes.POINTER(ctypes.c_float)]

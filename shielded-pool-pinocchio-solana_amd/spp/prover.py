@@ -164,6 +164,15 @@ class CircuitHandle:
         check(self.L.spp_timings(self.h, int(which), ms))
         return list(ms)
 
+    def msm_kernel_ms(self, which=0):
+        """durations of the MSM kernel launches of a batch: [commitment, A, B1, K, Z, PoK, G2] (spp_msm_kernel_ms)."""
+        ms = (ctypes.c_float * 7)()
+        check(self.L.spp_msm_kernel_ms(self.h, int(which), ms))
+        return list(ms)
+
+    def set_serial(self, on):
+        check(self.L.spp_set_serial(self.h, 1 if on else 0))
+
     def debug_witness(self):
         buf = ctypes.create_string_buffer(32 * self.n_wires)
         check(self.L.spp_debug_witness(self.h, ctypes.cast(buf, ctypes.c_void_p), self.n_wires))

@@ -36,3 +36,53 @@ def test_key_broadcast_and_sharding_world2(withdraw_artifacts):
     s0 = tuple(map(int, open(os.path.join(d, "s0")).read().split()))
     s1 = tuple(map(int, open(os.path.join(d, "s1")).read().split()))
     assert s0 == (0, 512) and s1 == (512, 1024)
+
+
+def _run_bench(extra, env_extra):
+    import json
+    import subprocess
+    env = dict(os.environ, SPP_BENCH_DRYRUN="1", SPP_BENCH_BACKEND="gloo", **env_extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        if k not in env_extra:
+            env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout            # ONE JSON line, from rank 0 only
+    return json.loads(lines[0])
+
+
+def test_bench_launcher_starts_n_ranks_and_prints_one_line():
+    """`python bench.py --gpus 2` with no launcher around it: bench.py itself starts 2 rank processes (before importing
+    torch), they rendezvous (gloo here, nccl = RCCL on the GPU box), broadcast the key blob, take their shard, time the
+    steps between barriers with MAX over ranks, and rank 0 prints one line claiming n_gpus = 2.  Dry run: the proving is
+    replaced by a sleep (there is no GPU in this container); the rest is the code path of the real run."""
+    j = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8"], {})
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["steps"] == 3 and j["config"]["dry_run"] is True
+    assert j["config"]["proofs_per_step_all_gpus"] == 16 and j["config"]["parallelism"] == "independent proofs x2"
+    assert abs(j["value"] - 16 / (j["ms_per_step"] * 1e-3)) / j["value"] < 0.01
+
+
+def test_bench_strong_mode_splits_a_fixed_batch():
+    """BASELINE.json configs[2]: a FIXED batch of 1024 audit proofs over the GPUs of a node -- strong scaling, contiguous
+    blocks from spp.multi.shard_range; with 3 ranks the blocks are 342 + 341 + 341."""
+    j = _run_bench(["--gpus", "3", "--steps", "2", "--mode", "strong", "--total", "1024"], {})
+    assert j["n_gpus"] == 3 and j["scaling"] == "strong" and j["config"]["proofs_per_step_all_gpus"] == 1024
+    j1 = _run_bench(["--gpus", "1", "--steps", "2", "--mode", "strong", "--total", "64"], {})
+    assert j1["n_gpus"] == 1 and j1["config"]["proofs_per_step_all_gpus"] == 64
+
+
+def test_bench_under_an_external_launcher():
+    """The driver's way: torch.distributed.run sets RANK / WORLD_SIZE and starts bench.py once per rank; bench.py must not
+    spawn again."""
+    import json
+    import subprocess
+    port = 29500 + ((os.getpid() + 777) % 2000)
+    env = dict(os.environ, SPP_BENCH_DRYRUN="1", SPP_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    assert json.loads(lines[0])["n_gpus"] == 2
