@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "bn254.hpp"
+#include "rlwe_ntt.hpp"
 
 namespace spp {
 
@@ -54,8 +55,20 @@ struct HashConsts {
 };
 
 // ---- stand-alone witness-input kernels (kernels_witness.hip) ----
-void launch_rlwe_witness(hipStream_t st, const uint32_t* pk_a, const uint32_t* pk_b, const int8_t* r, const int8_t* e1, const int8_t* e2,
-                         const uint8_t* msg, uint32_t* c0, uint32_t* c1, int32_t* k0, int32_t* k1, uint8_t* packed_be, uint32_t count);
+// device-resident constants of the RLWE witness kernel (rlwe_ntt.hpp) + scratch for the transformed public key
+struct RlwePkDev {
+  uint32_t hat[2][2][1024];   // [a | b][field][i]: NTT(pk psi^j)[i] / 1024, Montgomery form
+  uint32_t nzeros[2];
+  uint16_t zeros[2][1024];    // positions of zero coefficients (wrap correction)
+};
+struct RlweDev {
+  RnTables tb;
+  uint32_t pk_scale[2];
+  RlwePkDev* pk = nullptr;
+};
+void launch_rlwe_witness(hipStream_t st, const RlweDev& rd, const uint32_t* pk_a, const uint32_t* pk_b, const int8_t* r, const int8_t* e1,
+                         const int8_t* e2, const uint8_t* msg, uint32_t* c0, uint32_t* c1, int32_t* k0, int32_t* k1, uint8_t* packed_be,
+                         uint32_t count);
 void launch_poseidon_hash(hipStream_t st, HashConsts hc, const uint8_t* in_be, uint32_t arity, uint8_t* out_be, uint32_t count);
 void launch_merkle_path(hipStream_t st, HashConsts hc, const uint8_t* leaf_be, const uint64_t* index, const uint8_t* siblings_be,
                         uint32_t depth, uint8_t* root_be, uint32_t count);

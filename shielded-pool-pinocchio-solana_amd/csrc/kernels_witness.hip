@@ -10,109 +10,184 @@
 //   k_poseidon2_sponge    ct_helper/src/main.nr:15-34 (= scripts/generate_audit.py:355-374)
 #include "kernels.hpp"
 #include "poseidon29.hpp"
+#include "rlwe_ntt.hpp"
 
 namespace spp {
 
 // ----------------------------------------------------------------------------------------------------
-// RLWE: one 128-lane workgroup per instance.  The public key rows are negacyclic shifts of a (resp. b), so
-//   <row_i, r> = sum_j A2[(i - j) mod 2048] * r[j],  A2 = [a, (q - a) mod q]   (entries in [0,q), as the
-// reference's negacyclic_matrix_row_mod_q): each lane keeps 8 consecutive outputs in 64-bit accumulators and
-// slides an 8-entry window of A2 through registers, so one LDS read of A2 and one broadcast read of r[j] feed
-// 8 exact integer multiply-adds (v_mad_i64_i32; |sum| < 2^46).  Quotient and remainder by q follow Python's
-// floor semantics (generate_audit.py:241-242).
+// RLWE witness generation: one wavefront per instance, exact negacyclic products through a 1024-point NTT held in LDS
+// (rlwe_ntt.hpp: two prime fields q and 7*2^26+1, CRT digit = the quotient witness).  Per instance:
+//   forward transform of r (twisted by psi^j) in both fields                                   -> R
+//   R . NTT(a)/1024, inverse transform, untwist, CRT  -> c1[1024], k1[1024]   (generate_audit.py:517-518, 547-554)
+//   R . NTT(b)/1024, inverse transform, untwist, CRT  -> c0[64],   k0[64]     (:513-514, 539-545; slots 0..63 only)
+//   pack_values (:154-163) from LDS.
+// Lane t owns coefficients t + 64 j: every global access of a wave is a contiguous 64-element row.  The transforms of the
+// public key (k_rlwe_pk_ntt, once per call) use the same routine.
 // ----------------------------------------------------------------------------------------------------
 static constexpr int RL_N = 1024, RL_SLOTS = 64;
 static constexpr long long RL_Q = 167772161ll, RL_DELTA = 655360ll;
 
-__device__ __forceinline__ void floordiv_q(long long v, long long& k, uint32_t& rem) {
-  long long q = v / RL_Q, r = v % RL_Q;
-  if (r < 0) { r += RL_Q; q -= 1; }
-  k = q;
-  rem = (uint32_t)r;
+__device__ __forceinline__ void rn_ntt2(uint32_t lane, uint32_t (&x0)[16], uint32_t (&x1)[16], uint32_t* lds0, uint32_t* lds1,
+                                        const RnTables& tb, int dir) {
+  rn_pass1(lane, x0, lds0, tb.f[0], tb.w[0][dir], dir);
+  rn_pass1(lane, x1, lds1, tb.f[1], tb.w[1][dir], dir);
+  __syncthreads();
+  rn_pass2_read(lane, x0, lds0);
+  rn_pass2_read(lane, x1, lds1);
+  __syncthreads();
+  rn_pass2(lane, x0, lds0, tb.f[0], tb.w[0][dir], dir);
+  rn_pass2(lane, x1, lds1, tb.f[1], tb.w[1][dir], dir);
+  __syncthreads();
+  rn_pass3(lane, x0, lds0, tb.f[0], dir);
+  rn_pass3(lane, x1, lds1, tb.f[1], dir);
+  __syncthreads();
 }
 
-__global__ void __launch_bounds__(128) k_rlwe_witness(const uint32_t* __restrict__ pk_a, const uint32_t* __restrict__ pk_b,
-                                                      const int8_t* __restrict__ r_in, const int8_t* __restrict__ e1_in,
-                                                      const int8_t* __restrict__ e2_in, const uint8_t* __restrict__ msg_in,
-                                                      uint32_t* __restrict__ c0_out, uint32_t* __restrict__ c1_out,
-                                                      int32_t* __restrict__ k0_out, int32_t* __restrict__ k1_out,
-                                                      uint8_t* __restrict__ packed_be, uint32_t count) {
-  __shared__ int32_t A2[2 * RL_N];
-  __shared__ int32_t B2[2 * RL_N];
-  __shared__ int32_t rs[RL_N];
-  __shared__ uint32_t cs[RL_SLOTS + RL_N];   // c0 then c1, for the packing epilogue
-  const uint32_t inst = blockIdx.x;
-  if (inst >= count) return;
-  const int t = threadIdx.x;
-  for (int i = t; i < RL_N; i += 128) {
-    uint32_t a = pk_a[i], b = pk_b[i];
-    A2[i] = (int32_t)a;
-    A2[RL_N + i] = a ? (int32_t)(RL_Q - a) : 0;
-    B2[i] = (int32_t)b;
-    B2[RL_N + i] = b ? (int32_t)(RL_Q - b) : 0;
-    rs[i] = r_in[(size_t)inst * RL_N + i];
+// block 0: a, block 1: b.  hat[field][i] = NTT(pk psi^j)[i] / 1024 in Montgomery form (canonical), zero positions listed.
+__global__ void __launch_bounds__(64) k_rlwe_pk_ntt(RnTables tb, const uint32_t* __restrict__ pk_a, const uint32_t* __restrict__ pk_b,
+                                                    uint32_t pk_scale0, uint32_t pk_scale1, RlwePkDev* __restrict__ out) {
+  __shared__ uint32_t lds0[RN_LDS_WORDS];
+  __shared__ uint32_t lds1[RN_LDS_WORDS];
+  __shared__ uint32_t nz;
+  const uint32_t lane = threadIdx.x, poly = blockIdx.x;
+  const uint32_t* src = poly == 0 ? pk_a : pk_b;
+  if (lane == 0) nz = 0;
+  __syncthreads();
+  uint32_t x0[16], x1[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    const uint32_t i = lane + 64 * j, v = src[i];
+    if (v == 0) out->zeros[poly][atomicAdd(&nz, 1u)] = (uint16_t)i;
+    x0[j] = rn_mul(v, tb.psi[0][i], tb.f[0]);
+    x1[j] = rn_mul(v, tb.psi[1][i], tb.f[1]);
+  }
+  rn_ntt2(lane, x0, x1, lds0, lds1, tb, 0);
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    const uint32_t i = lane + 64 * j;
+    out->hat[poly][0][i] = rn_canon(rn_mul(x0[j], pk_scale0, tb.f[0]), tb.f[0]);
+    out->hat[poly][1][i] = rn_canon(rn_mul(x1[j], pk_scale1, tb.f[1]), tb.f[1]);
   }
   __syncthreads();
-  // ---- c1 / k1: outputs i0 .. i0+7 ----
+  if (lane == 0) out->nzeros[poly] = nz;
+}
+
+__global__ void __launch_bounds__(64) k_rlwe_witness(RnTables tb, const RlwePkDev* __restrict__ pk, const int8_t* __restrict__ r_in,
+                                                     const int8_t* __restrict__ e1_in, const int8_t* __restrict__ e2_in,
+                                                     const uint8_t* __restrict__ msg_in, uint32_t* __restrict__ c0_out,
+                                                     uint32_t* __restrict__ c1_out, int32_t* __restrict__ k0_out, int32_t* __restrict__ k1_out,
+                                                     uint8_t* __restrict__ packed_be, uint32_t count) {
+  __shared__ uint32_t lds0[RN_LDS_WORDS];
+  __shared__ uint32_t lds1[RN_LDS_WORDS];
+  __shared__ int32_t pre[RL_N + 64];          // prefix scan of r; afterwards c0 | c1 for the packing epilogue
+  __shared__ int8_t rbytes[RL_N];
+  const uint32_t inst = blockIdx.x, lane = threadIdx.x;
+  if (inst >= count) return;
+  // ---- r: one 16-byte load per lane, transposed through LDS to the lane layout i = lane + 64 j ----
+  reinterpret_cast<uint4*>(rbytes)[lane] = reinterpret_cast<const uint4*>(r_in + (size_t)inst * RL_N)[lane];
+  __syncthreads();
+  int32_t rv[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) rv[j] = rbytes[lane + 64 * j];
+  // ---- wrap correction: suffix sums of r (rlwe_ntt.hpp) ----
+  int32_t suffix[16];
   {
-    const int i0 = 8 * t;
-    long long acc[8];
+    rn_scan_scatter(lane, rv, pre);
+    __syncthreads();
+    rn_scan_chunk(lane, pre);
+    __syncthreads();
+    int32_t offset, total;
+    rn_scan_offsets(lane, pre, offset, total);
+    __syncthreads();
+    rn_scan_apply(lane, offset, pre);
+    __syncthreads();
+    rn_scan_gather(lane, total, pre, suffix);
+    __syncthreads();
+  }
+  // ---- forward transform of r in both fields ----
+  uint32_t R0[16], R1[16];
 #pragma unroll
-    for (int u = 0; u < 8; u++) acc[u] = 0;
-    int32_t win[8];   // win[u] = A2[(i0 + u - j) mod 2048]
+  for (int j = 0; j < 16; j++) {
+    const uint32_t i = lane + 64 * j;
+    const int32_t v = rv[j];
+    R0[j] = rn_mul(v < 0 ? (uint32_t)((int32_t)RN_P[0] + v) : (uint32_t)v, tb.psi[0][i], tb.f[0]);
+    R1[j] = rn_mul(v < 0 ? (uint32_t)((int32_t)RN_P[1] + v) : (uint32_t)v, tb.psi[1][i], tb.f[1]);
+  }
+  rn_ntt2(lane, R0, R1, lds0, lds1, tb, 0);
+  uint32_t* cs = reinterpret_cast<uint32_t*>(pre);   // c0 at [0,64), c1 at [64, 1088)
+  // ---- a: c1 / k1 ----
+  {
+    uint32_t y0[16], y1[16];
 #pragma unroll
-    for (int u = 0; u < 8; u++) win[u] = A2[(i0 + u) & 2047];
-    for (int j = 0; j < RL_N; j++) {
-      const int32_t rj = rs[j];
-#pragma unroll
-      for (int u = 0; u < 8; u++) acc[u] += (long long)win[u] * rj;
-      // slide: next j needs A2[i0 + u - (j+1)] = previous win[u-1]; new head A2[i0 - (j+1)]
-#pragma unroll
-      for (int u = 7; u > 0; u--) win[u] = win[u - 1];
-      win[0] = A2[(i0 - (j + 1)) & 2047];
+    for (int j = 0; j < 16; j++) {
+      const uint32_t i = lane + 64 * j;
+      y0[j] = rn_mul(R0[j], pk->hat[0][0][i], tb.f[0]);
+      y1[j] = rn_mul(R1[j], pk->hat[0][1][i], tb.f[1]);
     }
+    rn_ntt2(lane, y0, y1, lds0, lds1, tb, 1);
+    const uint32_t nz = pk->nzeros[0];
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int i = i0 + u;
-      long long k;
+    for (int j = 0; j < 16; j++) {
+      const uint32_t i = lane + 64 * j;
+      const uint32_t s0 = rn_canon(rn_mul(y0[j], tb.ipsi[0][i], tb.f[0]), tb.f[0]);
+      const uint32_t s1 = rn_canon(rn_mul(y1[j], tb.ipsi[1][i], tb.f[1]), tb.f[1]);
+      const int32_t t = rn_crt_digit(s0, s1, tb.f[1]);
+      int32_t k;
       uint32_t rem;
-      floordiv_q(acc[u] + (long long)e2_in[(size_t)inst * RL_N + i], k, rem);
+      rn_quot_rem(s0, t, (int32_t)e2_in[(size_t)inst * RL_N + i], k, rem);
+      k += suffix[j];
+      if (nz) k -= rn_zero_correction(i, pk->zeros[0], nz, rbytes);
       c1_out[(size_t)inst * RL_N + i] = rem;
-      k1_out[(size_t)inst * RL_N + i] = (int32_t)k;
+      k1_out[(size_t)inst * RL_N + i] = k;
       cs[RL_SLOTS + i] = rem;
     }
   }
-  // ---- c0 / k0: 64 outputs, one per lane of the first wave ----
-  if (t < RL_SLOTS) {
-    long long acc = 0;
-    for (int j = 0; j < RL_N; j++) acc += (long long)B2[(t - j) & 2047] * rs[j];
-    long long k;
+  // ---- b: c0 / k0 (message slots: coefficients 0..63 = element j = 0 of every lane) ----
+  {
+    uint32_t y0[16], y1[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const uint32_t i = lane + 64 * j;
+      y0[j] = rn_mul(R0[j], pk->hat[1][0][i], tb.f[0]);
+      y1[j] = rn_mul(R1[j], pk->hat[1][1][i], tb.f[1]);
+    }
+    rn_ntt2(lane, y0, y1, lds0, lds1, tb, 1);
+    const uint32_t nz = pk->nzeros[1];
+    const uint32_t i = lane;
+    const uint32_t s0 = rn_canon(rn_mul(y0[0], tb.ipsi[0][i], tb.f[0]), tb.f[0]);
+    const uint32_t s1 = rn_canon(rn_mul(y1[0], tb.ipsi[1][i], tb.f[1]), tb.f[1]);
+    const int32_t t = rn_crt_digit(s0, s1, tb.f[1]);
+    int32_t k;
     uint32_t rem;
-    floordiv_q(acc + (long long)e1_in[(size_t)inst * RL_SLOTS + t] + RL_DELTA * (long long)msg_in[(size_t)inst * RL_SLOTS + t], k, rem);
-    c0_out[(size_t)inst * RL_SLOTS + t] = rem;
-    k0_out[(size_t)inst * RL_SLOTS + t] = (int32_t)k;
-    cs[t] = rem;
+    rn_quot_rem(s0, t, (int32_t)e1_in[(size_t)inst * RL_SLOTS + i] + (int32_t)RL_DELTA * (int32_t)msg_in[(size_t)inst * RL_SLOTS + i], k, rem);
+    k += suffix[0];
+    if (nz) k -= rn_zero_correction(i, pk->zeros[1], nz, rbytes);
+    c0_out[(size_t)inst * RL_SLOTS + i] = rem;
+    k0_out[(size_t)inst * RL_SLOTS + i] = k;
+    cs[i] = rem;
   }
   __syncthreads();
-  // ---- pack 7 x 32-bit per field (pack_values), 32-byte big-endian: 10 + 147 fields ----
+  // ---- pack 7 x 32-bit per field (pack_values), 32-byte big-endian: 10 + 147 fields; one 32-bit word per lane and step ----
   if (packed_be) {
-    uint8_t* out = packed_be + (size_t)inst * 157 * 32;
-    for (int w = t; w < 157 * 8; w += 128) {
-      const int f = w / 8, jw = w % 8;            // jw-th little-endian 32-bit word of field f
+    uint32_t* out = reinterpret_cast<uint32_t*>(packed_be + (size_t)inst * 157 * 32);
+    for (uint32_t w = lane; w < 157 * 8; w += 64) {
+      const uint32_t f = w >> 3, wb = w & 7;      // wb-th big-endian word of field f  <->  little-endian word jw = 7 - wb
+      const uint32_t jw = 7 - wb;
       uint32_t v = 0;
       if (jw < 7) {
-        if (f < 10) { int idx = 7 * f + jw; if (idx < RL_SLOTS) v = cs[idx]; }
-        else { int idx = 7 * (f - 10) + jw; if (idx < RL_N) v = cs[RL_SLOTS + idx]; }
+        if (f < 10) { const uint32_t idx = 7 * f + jw; if (idx < RL_SLOTS) v = cs[idx]; }
+        else { const uint32_t idx = 7 * (f - 10) + jw; if (idx < RL_N) v = cs[RL_SLOTS + idx]; }
       }
-      uint8_t* o = out + f * 32 + (28 - 4 * jw);
-      o[0] = (uint8_t)(v >> 24); o[1] = (uint8_t)(v >> 16); o[2] = (uint8_t)(v >> 8); o[3] = (uint8_t)v;
+      out[w] = __builtin_bswap32(v);
     }
   }
 }
-void launch_rlwe_witness(hipStream_t st, const uint32_t* pk_a, const uint32_t* pk_b, const int8_t* r, const int8_t* e1, const int8_t* e2,
-                         const uint8_t* msg, uint32_t* c0, uint32_t* c1, int32_t* k0, int32_t* k1, uint8_t* packed_be, uint32_t count) {
+void launch_rlwe_witness(hipStream_t st, const RlweDev& rd, const uint32_t* pk_a, const uint32_t* pk_b, const int8_t* r, const int8_t* e1,
+                         const int8_t* e2, const uint8_t* msg, uint32_t* c0, uint32_t* c1, int32_t* k0, int32_t* k1, uint8_t* packed_be,
+                         uint32_t count) {
   if (count == 0) return;
-  hipLaunchKernelGGL(k_rlwe_witness, dim3(count), dim3(128), 0, st, pk_a, pk_b, r, e1, e2, msg, c0, c1, k0, k1, packed_be, count);
+  hipLaunchKernelGGL(k_rlwe_pk_ntt, dim3(2), dim3(64), 0, st, rd.tb, pk_a, pk_b, rd.pk_scale[0], rd.pk_scale[1], rd.pk);
+  hipLaunchKernelGGL(k_rlwe_witness, dim3(count), dim3(64), 0, st, rd.tb, rd.pk, r, e1, e2, msg, c0, c1, k0, k1, packed_be, count);
 }
 
 // ----------------------------------------------------------------------------------------------------

@@ -140,6 +140,8 @@ struct spp_ctx {
   bool consts_ready = false;
   HashConsts hc{};
   GkAffine* gk_table = nullptr;
+  bool rlwe_ready = false;
+  RlweDev rlwe{};              // NTT tables of the RLWE witness kernel (rlwe_ntt.hpp)
   std::vector<void*> owned;
 };
 
@@ -1437,6 +1439,32 @@ struct DevBuf {
     if (bytes) HIP_TRY(hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, st));      \
   } while (0)
 
+// twiddle / twist tables of the RLWE NTT kernel (32 KB) + the scratch that receives the transformed public key
+static int ensure_rlwe(spp_ctx* ctx) {
+  if (ctx->rlwe_ready) return 0;
+  static RnHostTables h;   // 33 KB: not on the stack
+  rn_build_tables(h);
+  RlweDev& rd = ctx->rlwe;
+  int e;
+  for (int k = 0; k < 2; k++) {
+    rd.tb.f[k] = h.f[k];
+    rd.pk_scale[k] = h.pk_scale[k];
+    uint32_t *w0, *w1, *ps, *ips;
+    if ((e = ctx_upload(ctx, &w0, std::vector<uint32_t>(h.w[k][0], h.w[k][0] + 1024))) ||
+        (e = ctx_upload(ctx, &w1, std::vector<uint32_t>(h.w[k][1], h.w[k][1] + 1024))) ||
+        (e = ctx_upload(ctx, &ps, std::vector<uint32_t>(h.psi[k], h.psi[k] + 1024))) ||
+        (e = ctx_upload(ctx, &ips, std::vector<uint32_t>(h.ipsi[k], h.ipsi[k] + 1024))))
+      return e;
+    rd.tb.w[k][0] = w0; rd.tb.w[k][1] = w1; rd.tb.psi[k] = ps; rd.tb.ipsi[k] = ips;
+  }
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, sizeof(RlwePkDev)));
+  ctx->owned.push_back(p);
+  rd.pk = (RlwePkDev*)p;
+  ctx->rlwe_ready = true;
+  return 0;
+}
+
 extern "C" int spp_rlwe_witness_batch(spp_ctx* ctx, const uint32_t* pk_a, const uint32_t* pk_b, size_t count, const int8_t* r,
                                       const int8_t* e1, const int8_t* e2, const uint8_t* msg, uint32_t* c0, uint32_t* c1, int32_t* k0,
                                       int32_t* k1, uint8_t* packed_be) {
@@ -1447,12 +1475,13 @@ extern "C" int spp_rlwe_witness_batch(spp_ctx* ctx, const uint32_t* pk_a, const 
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
+  if (int e = ensure_rlwe(ctx)) return e;
   DevBuf da, db, dr, de1, de2, dm, dc0, dc1, dk0, dk1, dp;
   UP(da, pk_a, 4096); UP(db, pk_b, 4096);
   UP(dr, r, count * 1024); UP(de1, e1, count * 64); UP(de2, e2, count * 1024); UP(dm, msg, count * 64);
   HIP_TRY(dc0.alloc(count * 64 * 4)); HIP_TRY(dc1.alloc(count * 1024 * 4)); HIP_TRY(dk0.alloc(count * 64 * 4)); HIP_TRY(dk1.alloc(count * 1024 * 4));
   if (packed_be) HIP_TRY(dp.alloc(count * 157 * 32));
-  launch_rlwe_witness(st, da.as<uint32_t>(), db.as<uint32_t>(), dr.as<int8_t>(), de1.as<int8_t>(), de2.as<int8_t>(), dm.as<uint8_t>(),
+  launch_rlwe_witness(st, ctx->rlwe, da.as<uint32_t>(), db.as<uint32_t>(), dr.as<int8_t>(), de1.as<int8_t>(), de2.as<int8_t>(), dm.as<uint8_t>(),
                       dc0.as<uint32_t>(), dc1.as<uint32_t>(), dk0.as<int32_t>(), dk1.as<int32_t>(), packed_be ? dp.as<uint8_t>() : nullptr,
                       (uint32_t)count);
   HIP_TRY(hipMemcpyAsync(c0, dc0.p, count * 64 * 4, hipMemcpyDeviceToHost, st));
@@ -1469,8 +1498,10 @@ extern "C" int spp_rlwe_witness_batch_device(spp_ctx* ctx, const void* d_pk_a, c
                                              const void* d_e1, const void* d_e2, const void* d_msg, void* d_c0, void* d_c1, void* d_k0,
                                              void* d_k1, void* d_packed_be) {
   if (!ctx) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_TRY(hipSetDevice(ctx->device));
-  launch_rlwe_witness(ctx->stream, (const uint32_t*)d_pk_a, (const uint32_t*)d_pk_b, (const int8_t*)d_r, (const int8_t*)d_e1,
+  if (int e = ensure_rlwe(ctx)) return e;
+  launch_rlwe_witness(ctx->stream, ctx->rlwe, (const uint32_t*)d_pk_a, (const uint32_t*)d_pk_b, (const int8_t*)d_r, (const int8_t*)d_e1,
                       (const int8_t*)d_e2, (const uint8_t*)d_msg, (uint32_t*)d_c0, (uint32_t*)d_c1, (int32_t*)d_k0, (int32_t*)d_k1,
                       (uint8_t*)d_packed_be, (uint32_t)count);
   HIP_TRY(hipGetLastError());
@@ -1917,7 +1948,8 @@ static int audit_inputs_on_device(spp_ctx* ctx, const uint32_t* d_pk_a, const ui
   launch_grumpkin_keygen(st, ctx->gk_table, d_sk, xy.as<uint8_t>(), count);                       // generate_audit.py:482
   launch_poseidon_hash(st, ctx->hc, xy.as<uint8_t>(), 2, wa.as<uint8_t>(), count);                 // wa_commitment
   launch_audit_msg(st, xy.as<uint8_t>(), msg.as<uint8_t>(), count);                                // :489-496
-  launch_rlwe_witness(st, d_pk_a, d_pk_b, d_r, d_e1, d_e2, msg.as<uint8_t>(), c0.as<uint32_t>(), c1.as<uint32_t>(), k0.as<int32_t>(),
+  if (int e = ensure_rlwe(ctx)) return e;
+  launch_rlwe_witness(st, ctx->rlwe, d_pk_a, d_pk_b, d_r, d_e1, d_e2, msg.as<uint8_t>(), c0.as<uint32_t>(), c1.as<uint32_t>(), k0.as<int32_t>(),
                       k1.as<int32_t>(), packed.as<uint8_t>(), count);                              // :507-584
   launch_poseidon2_sponge(st, ctx->hc, packed.as<uint8_t>(), 157, ct.as<uint8_t>(), count);        // ct_commitment :587
   launch_audit_assemble(st, wa.as<uint8_t>(), ct.as<uint8_t>(), packed.as<uint8_t>(), d_sk, d_r, d_e1, d_e2, k0.as<int32_t>(),
