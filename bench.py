@@ -117,7 +117,7 @@ def dry_run(args, rank, world, dist, coll_dev):
                                      "proofs_per_step_all_gpus": total, "parallelism": "independent proofs x%d" % world}}), flush=True)
 
 
-def rlwe_leg(ctx, dev, pk, iters=10):
+def rlwe_leg(ctx, dev, pk, iters=200):
     """BASELINE.json configs[3]: RLWE negacyclic witness generation, 2^16 instances on one GPU (scripts/generate_audit.py:507-584)."""
     import ctypes
     import numpy as np

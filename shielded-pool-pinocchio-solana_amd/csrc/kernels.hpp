@@ -57,13 +57,13 @@ struct HashConsts {
 // ---- stand-alone witness-input kernels (kernels_witness.hip) ----
 // device-resident constants of the RLWE witness kernel (rlwe_ntt.hpp) + scratch for the transformed public key
 struct RlwePkDev {
-  uint32_t hat[2][2][1024];   // [a | b][field][i]: NTT(pk psi^j)[i] / 1024, Montgomery form
+  int32_t hat[2][2][1024];    // [a | b][field][i]: NTT(pk psi^j)[i] / 1024, Montgomery form, in (-p, p)
   uint32_t nzeros[2];
   uint16_t zeros[2][1024];    // positions of zero coefficients (wrap correction)
 };
 struct RlweDev {
   RnTables tb;
-  uint32_t pk_scale[2];
+  int32_t pk_scale[2];
   RlwePkDev* pk = nullptr;
 };
 void launch_rlwe_witness(hipStream_t st, const RlweDev& rd, const uint32_t* pk_a, const uint32_t* pk_b, const int8_t* r, const int8_t* e1,

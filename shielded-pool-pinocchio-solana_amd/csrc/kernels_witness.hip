@@ -27,116 +27,135 @@ namespace spp {
 static constexpr int RL_N = 1024, RL_SLOTS = 64;
 static constexpr long long RL_Q = 167772161ll, RL_DELTA = 655360ll;
 
-__device__ __forceinline__ void rn_ntt2(uint32_t lane, uint32_t (&x0)[16], uint32_t (&x1)[16], uint32_t* lds0, uint32_t* lds1,
-                                        const RnTables& tb, int dir) {
-  rn_pass1(lane, x0, lds0, tb.f[0], tb.w[0][dir], dir);
-  rn_pass1(lane, x1, lds1, tb.f[1], tb.w[1][dir], dir);
+template <bool REDUCE>
+__device__ __forceinline__ void rn_ntt1(uint32_t lane, int32_t (&x)[16], int32_t* lds, const RnField& f, const int32_t* w, int dir) {
+  rn_pass1<REDUCE>(lane, x, lds, f, w, dir);
   __syncthreads();
-  rn_pass2_read(lane, x0, lds0);
-  rn_pass2_read(lane, x1, lds1);
+  rn_pass2_read(lane, x, lds);
   __syncthreads();
-  rn_pass2(lane, x0, lds0, tb.f[0], tb.w[0][dir], dir);
-  rn_pass2(lane, x1, lds1, tb.f[1], tb.w[1][dir], dir);
+  rn_pass2<REDUCE>(lane, x, lds, f, w, dir);
   __syncthreads();
-  rn_pass3(lane, x0, lds0, tb.f[0], dir);
-  rn_pass3(lane, x1, lds1, tb.f[1], dir);
+  rn_pass3(lane, x, lds, f, dir);
   __syncthreads();
 }
 
-// block 0: a, block 1: b.  hat[field][i] = NTT(pk psi^j)[i] / 1024 in Montgomery form (canonical), zero positions listed.
+// block 0: a, block 1: b.  hat[field][i] = NTT(pk psi^j)[i] / 1024 in Montgomery form, zero positions listed.
 __global__ void __launch_bounds__(64) k_rlwe_pk_ntt(RnTables tb, const uint32_t* __restrict__ pk_a, const uint32_t* __restrict__ pk_b,
-                                                    uint32_t pk_scale0, uint32_t pk_scale1, RlwePkDev* __restrict__ out) {
-  __shared__ uint32_t lds0[RN_LDS_WORDS];
-  __shared__ uint32_t lds1[RN_LDS_WORDS];
+                                                    int32_t pk_scale0, int32_t pk_scale1, RlwePkDev* __restrict__ out) {
+  __shared__ int32_t lds[RN_LDS_WORDS];
   __shared__ uint32_t nz;
   const uint32_t lane = threadIdx.x, poly = blockIdx.x;
   const uint32_t* src = poly == 0 ? pk_a : pk_b;
   if (lane == 0) nz = 0;
   __syncthreads();
-  uint32_t x0[16], x1[16];
+  int32_t x[16];
 #pragma unroll
   for (int j = 0; j < 16; j++) {
     const uint32_t i = lane + 64 * j, v = src[i];
     if (v == 0) out->zeros[poly][atomicAdd(&nz, 1u)] = (uint16_t)i;
-    x0[j] = rn_mul(v, tb.psi[0][i], tb.f[0]);
-    x1[j] = rn_mul(v, tb.psi[1][i], tb.f[1]);
+    x[j] = rn_mul((int32_t)v, tb.psi[0][i], tb.f[0]);
   }
-  rn_ntt2(lane, x0, x1, lds0, lds1, tb, 0);
+  rn_ntt1<true>(lane, x, lds, tb.f[0], tb.w[0][0], 0);
 #pragma unroll
-  for (int j = 0; j < 16; j++) {
-    const uint32_t i = lane + 64 * j;
-    out->hat[poly][0][i] = rn_canon(rn_mul(x0[j], pk_scale0, tb.f[0]), tb.f[0]);
-    out->hat[poly][1][i] = rn_canon(rn_mul(x1[j], pk_scale1, tb.f[1]), tb.f[1]);
-  }
+  for (int j = 0; j < 16; j++) out->hat[poly][0][lane + 64 * j] = rn_mul(x[j], pk_scale0, tb.f[0]);
+#pragma unroll
+  for (int j = 0; j < 16; j++) x[j] = rn_mul((int32_t)src[lane + 64 * j], tb.psi[1][lane + 64 * j], tb.f[1]);
+  rn_ntt1<false>(lane, x, lds, tb.f[1], tb.w[1][0], 0);
+#pragma unroll
+  for (int j = 0; j < 16; j++) out->hat[poly][1][lane + 64 * j] = rn_mul(x[j], pk_scale1, tb.f[1]);
   __syncthreads();
   if (lane == 0) out->nzeros[poly] = nz;
 }
 
-__global__ void __launch_bounds__(64) k_rlwe_witness(RnTables tb, const RlwePkDev* __restrict__ pk, const int8_t* __restrict__ r_in,
-                                                     const int8_t* __restrict__ e1_in, const int8_t* __restrict__ e2_in,
-                                                     const uint8_t* __restrict__ msg_in, uint32_t* __restrict__ c0_out,
-                                                     uint32_t* __restrict__ c1_out, int32_t* __restrict__ k0_out, int32_t* __restrict__ k1_out,
-                                                     uint8_t* __restrict__ packed_be, uint32_t count) {
-  __shared__ uint32_t lds0[RN_LDS_WORDS];
-  __shared__ uint32_t lds1[RN_LDS_WORDS];
-  __shared__ int32_t pre[RL_N + 64];          // prefix scan of r; afterwards c0 | c1 for the packing epilogue
+// out[j] = (R . hat) transformed back (before the untwist) at coefficient lane + 64 j, field K
+template <int K>
+__device__ __forceinline__ void rn_product(uint32_t lane, const int32_t (&R)[16], const int32_t* __restrict__ hat, int32_t (&out)[16],
+                                           int32_t* lds, const RnTables& tb) {
+#pragma unroll
+  for (int j = 0; j < 16; j++) out[j] = rn_mul(R[j], hat[lane + 64 * j], tb.f[K]);
+  rn_ntt1<K == 0>(lane, out, lds, tb.f[K], tb.w[K][1], 1);
+}
+
+// coefficient `lane` (< 64) of the same product through the pruned inverse transform
+template <int K>
+__device__ __forceinline__ int32_t rn_product_first64(uint32_t lane, const int32_t (&R)[16], const int32_t* __restrict__ hat, int32_t* lds,
+                                                      const RnTables& tb) {
+  int32_t x[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) x[j] = rn_mul(R[j], hat[lane + 64 * j], tb.f[K]);
+  rn_pass1<K == 0>(lane, x, lds, tb.f[K], tb.w[K][1], 1);
+  __syncthreads();
+  rn_pass2_read(lane, x, lds);
+  __syncthreads();
+  rn_pass2_first64<K == 0>(lane, x, lds, tb.f[K], tb.w[K][1], 1);
+  __syncthreads();
+  const int32_t v = rn_pass3_first64(lane, lds);
+  __syncthreads();
+  return v;
+}
+
+__global__ void __launch_bounds__(64, 4) k_rlwe_witness(RnTables tb, const RlwePkDev* __restrict__ pk, const int8_t* __restrict__ r_in,
+                                                        const int8_t* __restrict__ e1_in, const int8_t* __restrict__ e2_in,
+                                                        const uint8_t* __restrict__ msg_in, uint32_t* __restrict__ c0_out,
+                                                        uint32_t* __restrict__ c1_out, int32_t* __restrict__ k0_out,
+                                                        int32_t* __restrict__ k1_out, uint8_t* __restrict__ packed_be, uint32_t count) {
+  __shared__ int32_t lds[RN_LDS_WORDS];       // exchange buffer of the transform in flight (one field at a time)
+  __shared__ int32_t pre[RL_N + 64];          // prefix scan of r -> suffix sums at [64 + i]; then c0 | c1 for the packing epilogue
   __shared__ int8_t rbytes[RL_N];
+  __shared__ int32_t tot[64], offs[64];
   const uint32_t inst = blockIdx.x, lane = threadIdx.x;
   if (inst >= count) return;
   // ---- r: one 16-byte load per lane, transposed through LDS to the lane layout i = lane + 64 j ----
   reinterpret_cast<uint4*>(rbytes)[lane] = reinterpret_cast<const uint4*>(r_in + (size_t)inst * RL_N)[lane];
   __syncthreads();
-  int32_t rv[16];
-#pragma unroll
-  for (int j = 0; j < 16; j++) rv[j] = rbytes[lane + 64 * j];
-  // ---- wrap correction: suffix sums of r (rlwe_ntt.hpp) ----
-  int32_t suffix[16];
+  int32_t R0[16], R1[16];
+  int32_t suffix0;   // wrap correction of coefficient `lane` (needed again for the message slots)
   {
+    int32_t rv[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) rv[j] = rbytes[lane + 64 * j];
+    // forward transforms of r psi^j in both fields
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const uint32_t i = lane + 64 * j;
+      R0[j] = rn_mul(rv[j], tb.psi[0][i], tb.f[0]);     // signed arithmetic: r_j in [-128, 127] goes in as it is
+      R1[j] = rn_mul(rv[j], tb.psi[1][i], tb.f[1]);
+    }
+    // wrap correction: suffix sums of r (rlwe_ntt.hpp), left in LDS at pre[64 + i] (the slot that later receives c1[i])
     rn_scan_scatter(lane, rv, pre);
     __syncthreads();
-    rn_scan_chunk(lane, pre);
+    rn_scan_chunk(lane, pre, tot);
     __syncthreads();
     int32_t offset, total;
-    rn_scan_offsets(lane, pre, offset, total);
+    rn_scan_offsets(lane, tot, offset, total);
+    offs[lane] = offset;
     __syncthreads();
-    rn_scan_apply(lane, offset, pre);
+    int32_t suffix[16];
+    rn_scan_gather(lane, total, pre, offs, suffix);
     __syncthreads();
-    rn_scan_gather(lane, total, pre, suffix);
-    __syncthreads();
-  }
-  // ---- forward transform of r in both fields ----
-  uint32_t R0[16], R1[16];
 #pragma unroll
-  for (int j = 0; j < 16; j++) {
-    const uint32_t i = lane + 64 * j;
-    const int32_t v = rv[j];
-    R0[j] = rn_mul(v < 0 ? (uint32_t)((int32_t)RN_P[0] + v) : (uint32_t)v, tb.psi[0][i], tb.f[0]);
-    R1[j] = rn_mul(v < 0 ? (uint32_t)((int32_t)RN_P[1] + v) : (uint32_t)v, tb.psi[1][i], tb.f[1]);
+    for (int j = 0; j < 16; j++) pre[64 + lane + 64 * j] = suffix[j];
+    suffix0 = suffix[0];
   }
-  rn_ntt2(lane, R0, R1, lds0, lds1, tb, 0);
+  rn_ntt1<true>(lane, R0, lds, tb.f[0], tb.w[0][0], 0);
+  rn_ntt1<false>(lane, R1, lds, tb.f[1], tb.w[1][0], 0);
   uint32_t* cs = reinterpret_cast<uint32_t*>(pre);   // c0 at [0,64), c1 at [64, 1088)
   // ---- a: c1 / k1 ----
   {
-    uint32_t y0[16], y1[16];
+    int32_t s0[16], y[16];
+    rn_product<0>(lane, R0, pk->hat[0][0], s0, lds, tb);
+#pragma unroll
+    for (int j = 0; j < 16; j++) s0[j] = rn_canon(rn_mul(s0[j], tb.ipsi[0][lane + 64 * j], tb.f[0]), tb.f[0]);
+    rn_product<1>(lane, R1, pk->hat[0][1], y, lds, tb);
 #pragma unroll
     for (int j = 0; j < 16; j++) {
       const uint32_t i = lane + 64 * j;
-      y0[j] = rn_mul(R0[j], pk->hat[0][0][i], tb.f[0]);
-      y1[j] = rn_mul(R1[j], pk->hat[0][1][i], tb.f[1]);
-    }
-    rn_ntt2(lane, y0, y1, lds0, lds1, tb, 1);
-    const uint32_t nz = pk->nzeros[0];
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-      const uint32_t i = lane + 64 * j;
-      const uint32_t s0 = rn_canon(rn_mul(y0[j], tb.ipsi[0][i], tb.f[0]), tb.f[0]);
-      const uint32_t s1 = rn_canon(rn_mul(y1[j], tb.ipsi[1][i], tb.f[1]), tb.f[1]);
-      const int32_t t = rn_crt_digit(s0, s1, tb.f[1]);
+      const int32_t s1 = rn_canon(rn_mul(y[j], tb.ipsi[1][i], tb.f[1]), tb.f[1]);
+      const int32_t t = rn_crt_digit(s0[j], s1, tb.f[1]);
       int32_t k;
       uint32_t rem;
-      rn_quot_rem(s0, t, (int32_t)e2_in[(size_t)inst * RL_N + i], k, rem);
-      k += suffix[j];
-      if (nz) k -= rn_zero_correction(i, pk->zeros[0], nz, rbytes);
+      rn_quot_rem(s0[j], t, (int32_t)e2_in[(size_t)inst * RL_N + i], k, rem);
+      k += pre[64 + i];                 // own slot: read the suffix sum, then overwrite it with the remainder
       c1_out[(size_t)inst * RL_N + i] = rem;
       k1_out[(size_t)inst * RL_N + i] = k;
       cs[RL_SLOTS + i] = rem;
@@ -144,35 +163,37 @@ __global__ void __launch_bounds__(64) k_rlwe_witness(RnTables tb, const RlwePkDe
   }
   // ---- b: c0 / k0 (message slots: coefficients 0..63 = element j = 0 of every lane) ----
   {
-    uint32_t y0[16], y1[16];
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-      const uint32_t i = lane + 64 * j;
-      y0[j] = rn_mul(R0[j], pk->hat[1][0][i], tb.f[0]);
-      y1[j] = rn_mul(R1[j], pk->hat[1][1][i], tb.f[1]);
-    }
-    rn_ntt2(lane, y0, y1, lds0, lds1, tb, 1);
-    const uint32_t nz = pk->nzeros[1];
+    const int32_t y0 = rn_product_first64<0>(lane, R0, pk->hat[1][0], lds, tb);
+    const int32_t y1 = rn_product_first64<1>(lane, R1, pk->hat[1][1], lds, tb);
     const uint32_t i = lane;
-    const uint32_t s0 = rn_canon(rn_mul(y0[0], tb.ipsi[0][i], tb.f[0]), tb.f[0]);
-    const uint32_t s1 = rn_canon(rn_mul(y1[0], tb.ipsi[1][i], tb.f[1]), tb.f[1]);
+    const int32_t s0 = rn_canon(rn_mul(y0, tb.ipsi[0][i], tb.f[0]), tb.f[0]);
+    const int32_t s1 = rn_canon(rn_mul(y1, tb.ipsi[1][i], tb.f[1]), tb.f[1]);
     const int32_t t = rn_crt_digit(s0, s1, tb.f[1]);
     int32_t k;
     uint32_t rem;
     rn_quot_rem(s0, t, (int32_t)e1_in[(size_t)inst * RL_SLOTS + i] + (int32_t)RL_DELTA * (int32_t)msg_in[(size_t)inst * RL_SLOTS + i], k, rem);
-    k += suffix[0];
-    if (nz) k -= rn_zero_correction(i, pk->zeros[1], nz, rbytes);
+    k += suffix0;
     c0_out[(size_t)inst * RL_SLOTS + i] = rem;
     k0_out[(size_t)inst * RL_SLOTS + i] = k;
     cs[i] = rem;
+  }
+  // ---- rare: the public key has zero coefficients (probability 1/q each): the wrapped term is 0, not q * r_j ----
+  const uint32_t nza = pk->nzeros[0], nzb = pk->nzeros[1];
+  if (nza | nzb) {
+    if (nza)
+#pragma unroll 1
+      for (uint32_t j = 0; j < 16; j++) {
+        const uint32_t i = lane + 64 * j;
+        k1_out[(size_t)inst * RL_N + i] -= rn_zero_correction(i, pk->zeros[0], nza, rbytes);
+      }
+    if (nzb) k0_out[(size_t)inst * RL_SLOTS + lane] -= rn_zero_correction(lane, pk->zeros[1], nzb, rbytes);
   }
   __syncthreads();
   // ---- pack 7 x 32-bit per field (pack_values), 32-byte big-endian: 10 + 147 fields; one 32-bit word per lane and step ----
   if (packed_be) {
     uint32_t* out = reinterpret_cast<uint32_t*>(packed_be + (size_t)inst * 157 * 32);
     for (uint32_t w = lane; w < 157 * 8; w += 64) {
-      const uint32_t f = w >> 3, wb = w & 7;      // wb-th big-endian word of field f  <->  little-endian word jw = 7 - wb
-      const uint32_t jw = 7 - wb;
+      const uint32_t f = w >> 3, jw = 7 - (w & 7);      // big-endian word w & 7 of field f  <->  little-endian word jw
       uint32_t v = 0;
       if (jw < 7) {
         if (f < 10) { const uint32_t idx = 7 * f + jw; if (idx < RL_SLOTS) v = cs[idx]; }

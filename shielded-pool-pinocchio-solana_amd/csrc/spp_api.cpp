@@ -1449,13 +1449,14 @@ static int ensure_rlwe(spp_ctx* ctx) {
   for (int k = 0; k < 2; k++) {
     rd.tb.f[k] = h.f[k];
     rd.pk_scale[k] = h.pk_scale[k];
-    uint32_t *w0, *w1, *ps, *ips;
-    if ((e = ctx_upload(ctx, &w0, std::vector<uint32_t>(h.w[k][0], h.w[k][0] + 1024))) ||
-        (e = ctx_upload(ctx, &w1, std::vector<uint32_t>(h.w[k][1], h.w[k][1] + 1024))) ||
-        (e = ctx_upload(ctx, &ps, std::vector<uint32_t>(h.psi[k], h.psi[k] + 1024))) ||
-        (e = ctx_upload(ctx, &ips, std::vector<uint32_t>(h.ipsi[k], h.ipsi[k] + 1024))))
+    int32_t *w0, *w1, *ps, *ips;
+    if ((e = ctx_upload(ctx, &w0, std::vector<int32_t>(h.w[k][0], h.w[k][0] + 1024))) ||
+        (e = ctx_upload(ctx, &w1, std::vector<int32_t>(h.w[k][1], h.w[k][1] + 1024))) ||
+        (e = ctx_upload(ctx, &ps, std::vector<int32_t>(h.psi[k], h.psi[k] + 1024))) ||
+        (e = ctx_upload(ctx, &ips, std::vector<int32_t>(h.ipsi[k], h.ipsi[k] + 1024))))
       return e;
     rd.tb.w[k][0] = w0; rd.tb.w[k][1] = w1; rd.tb.psi[k] = ps; rd.tb.ipsi[k] = ips;
+
   }
   void* p = nullptr;
   HIP_TRY(hipMalloc(&p, sizeof(RlwePkDev)));

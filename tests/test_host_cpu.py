@@ -265,6 +265,18 @@ def test_f29_unsaturated_arithmetic_host_check(tmp_path):
     assert out.strip().splitlines()[-1].startswith("OK "), out
 
 
+def test_rlwe_lds_ntt_phases_host_check(tmp_path):
+    """csrc/rlwe_ntt.hpp: the per-lane phases of the RLWE witness kernel's 1024-point LDS NTT (two primes + CRT digit + wrap
+    correction), run lane by lane on the host against the schoolbook definition of scripts/generate_audit.py:45-66,236-243 --
+    random, extremal (a = q-1, r = +-128, e = +-128, m = 255), zero and sparse public keys -- plus the derived growth bounds
+    of the lazy signed arithmetic."""
+    exe = str(tmp_path / "rlwe_ntt_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "shielded-pool-pinocchio-solana_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "host", "rlwe_ntt_check.cpp"), "-o", exe], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert out.strip().splitlines()[-1].startswith("OK rlwe_ntt"), out
+
+
 def test_f29_limb_bounds_certificate():
     """Interval arithmetic over the generated constants: no 64-bit column can overflow, every lifted subtraction
     constant dominates its subtrahend, and the accumulator's value bounds are inductive."""
