@@ -1,0 +1,394 @@
+"""ACIR / nargo artefact ingestion: the files the reference's proving pipeline passes between `nargo execute`
+and `sunspot prove` (client/proof.helper.ts:58-66: target/<name>.json, target/<name>.gz).
+
+    load_program(path | dict)         target/<name>.json  -- {noir_version, abi, bytecode = base64(gzip(bincode Program))}
+    read_witness_stack(path)          target/<name>.gz    -- gzip(bincode WitnessStack)      (what `nargo execute` writes)
+    write_witness_stack(path, map)    the inverse (tests, and tools that want to hand a witness to other ACIR consumers)
+    abi_input_row(program, witness)   the circuit's input wires in ABI order = the Prover.toml order of proof.helper.ts:34-50
+    r1cs_rows(circuit)                the AssertZero opcodes as R1CS rows  (qM * w_a) * w_b = -(linear part)
+
+Format (noir 1.0.0-beta.18, decoded from the reference's own shielded_pool_verifier.json): bincode with
+fixed-width little-endian integers --
+  Program   = u64 nFunctions . Circuit* . u64 nUnconstrained . BrilligBytecode*      (the Brillig functions are not decoded)
+  Circuit   = String name . u32 current_witness_index . u64 nOpcodes . Opcode* . BTreeSet<Witness> private_parameters
+              . BTreeSet<Witness> public_parameters . BTreeSet<Witness> return_values . assert_messages ...
+  Opcode    = u32 tag: 0 AssertZero(Expression) | 1 BlackBoxFuncCall | 2 MemoryOp | 3 MemoryInit | 4 BrilligCall | 5 Call
+  Expression= Vec<(F, W, W)> mul_terms . Vec<(F, W)> linear . F constant ;  F = u64 32 . 32 bytes big-endian ; W = u32
+  BlackBox  = u32 tag: 3 RANGE {FunctionInput, u32 bits} | 8 MultiScalarMul {Vec<FunctionInput> points, Vec<FunctionInput>
+              scalars, FunctionInput predicate, (W, W, W) outputs} ;  FunctionInput = u32 tag (0 constant F | 1 witness W)
+  BrilligCall = u32 id . Vec<BrilligInputs> (u32 tag: 0 Single Expression | 1 Array Vec<Expression> | 2 MemoryArray u32)
+              . Vec<BrilligOutputs> (u32 tag: 0 Simple W | 1 Array Vec<W>) . Option<Expression> predicate (u8 tag)
+Only the variants that occur in the reference's circuits are implemented; anything else raises AcirFormatError naming the tag
+and the byte offset.  This module is pure host code (no GPU): it turns files into input rows for spp_prove_batch.
+"""
+import base64
+import gzip
+import json
+import struct
+
+R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+class AcirFormatError(ValueError):
+    pass
+
+
+class _Reader:
+    def __init__(self, data):
+        self.d, self.o = data, 0
+
+    def u8(self):
+        v = self.d[self.o]
+        self.o += 1
+        return v
+
+    def u32(self):
+        v = struct.unpack_from("<I", self.d, self.o)[0]
+        self.o += 4
+        return v
+
+    def u64(self):
+        v = struct.unpack_from("<Q", self.d, self.o)[0]
+        self.o += 8
+        return v
+
+    def field(self):
+        n = self.u64()
+        if n != 32:
+            raise AcirFormatError("field element of %d bytes at offset %d" % (n, self.o - 8))
+        v = int.from_bytes(self.d[self.o:self.o + 32], "big")
+        self.o += 32
+        return v
+
+    def string(self):
+        n = self.u64()
+        s = self.d[self.o:self.o + n].decode()
+        self.o += n
+        return s
+
+    def vec(self, item):
+        return [item() for _ in range(self.u64())]
+
+
+class Expression:
+    __slots__ = ("mul_terms", "linear", "constant")
+
+    def __init__(self, mul_terms, linear, constant):
+        self.mul_terms, self.linear, self.constant = mul_terms, linear, constant
+
+    def evaluate(self, w):
+        s = self.constant
+        for c, a, b in self.mul_terms:
+            s += c * w[a] * w[b]
+        for c, a in self.linear:
+            s += c * w[a]
+        return s % R
+
+
+def _expression(r):
+    mul = r.vec(lambda: (r.field(), r.u32(), r.u32()))
+    lin = r.vec(lambda: (r.field(), r.u32()))
+    return Expression(mul, lin, r.field())
+
+
+def _function_input(r):
+    tag = r.u32()
+    if tag == 0:
+        return ("constant", r.field())
+    if tag == 1:
+        return ("witness", r.u32())
+    raise AcirFormatError("FunctionInput tag %d at offset %d" % (tag, r.o - 4))
+
+
+def _opcode(r):
+    at = r.o
+    tag = r.u32()
+    if tag == 0:
+        return ("AssertZero", _expression(r))
+    if tag == 1:
+        bb = r.u32()
+        if bb == 3:
+            return ("RANGE", _function_input(r), r.u32())
+        if bb == 8:
+            points = r.vec(lambda: _function_input(r))
+            scalars = r.vec(lambda: _function_input(r))
+            predicate = _function_input(r)
+            return ("MultiScalarMul", points, scalars, predicate, (r.u32(), r.u32(), r.u32()))
+        raise AcirFormatError("BlackBoxFuncCall %d at offset %d is not used by the reference's circuits" % (bb, at))
+    if tag == 4:
+        fid = r.u32()
+
+        def binput():
+            t = r.u32()
+            if t == 0:
+                return ("single", _expression(r))
+            if t == 1:
+                return ("array", r.vec(lambda: _expression(r)))
+            if t == 2:
+                return ("memory", r.u32())
+            raise AcirFormatError("BrilligInputs tag %d at offset %d" % (t, r.o - 4))
+
+        def boutput():
+            t = r.u32()
+            if t == 0:
+                return ("simple", r.u32())
+            if t == 1:
+                return ("array", r.vec(r.u32))
+            raise AcirFormatError("BrilligOutputs tag %d at offset %d" % (t, r.o - 4))
+        inputs = r.vec(binput)
+        outputs = r.vec(boutput)
+        predicate = _expression(r) if r.u8() else None
+        return ("BrilligCall", fid, inputs, outputs, predicate)
+    raise AcirFormatError("opcode tag %d at offset %d is not used by the reference's circuits" % (tag, at))
+
+
+class Circuit:
+    def __init__(self, r):
+        self.name = r.string()
+        self.current_witness_index = r.u32()
+        self.opcodes = r.vec(lambda: _opcode(r))
+        self.private_parameters = r.vec(r.u32)
+        self.public_parameters = r.vec(r.u32)
+        self.return_values = r.vec(r.u32)
+        self.end_of_parameters = r.o      # assert messages and the Brillig functions follow (not decoded)
+
+    def histogram(self):
+        h = {}
+        for op in self.opcodes:
+            h[op[0]] = h.get(op[0], 0) + 1
+        return h
+
+
+class Program:
+    def __init__(self, doc):
+        self.noir_version = doc.get("noir_version")
+        self.abi = doc["abi"]
+        self.raw = gzip.decompress(base64.b64decode(doc["bytecode"]))
+        r = _Reader(self.raw)
+        n = r.u64()
+        if n != 1:
+            raise AcirFormatError("%d ACIR functions (the reference's programs have one)" % n)
+        self.main = Circuit(r)
+
+    def parameter_witnesses(self):
+        """[(name, [witness indices])] in ABI order: parameters occupy consecutive witnesses from 0 (nargo's ABI encoding)."""
+        out, nxt = [], 0
+        for p in self.abi["parameters"]:
+            n = p["type"]["length"] if p["type"]["kind"] == "array" else 1
+            out.append((p["name"], list(range(nxt, nxt + n))))
+            nxt += n
+        return out
+
+
+def load_program(src):
+    return Program(src if isinstance(src, dict) else json.load(open(src)))
+
+
+# ---- witness stacks (target/<name>.gz) ----
+def write_witness_stack(path, witness_map, index=0):
+    """gzip(bincode WitnessStack{stack: [StackItem{index, witness: BTreeMap<Witness, F>}]}) -- the layout `nargo execute` writes."""
+    body = struct.pack("<Q", 1) + struct.pack("<I", index) + struct.pack("<Q", len(witness_map))
+    for k in sorted(witness_map):
+        body += struct.pack("<I", k) + struct.pack("<Q", 32) + int(witness_map[k] % R).to_bytes(32, "big")
+    with open(path, "wb") as f:
+        f.write(gzip.compress(body))
+
+
+def read_witness_stack(path):
+    """Returns the witness map {index: value} of the LAST stack item (the main function), as sunspot / bb consume it."""
+    r = _Reader(gzip.decompress(open(path, "rb").read()))
+    items = r.u64()
+    if items == 0:
+        raise AcirFormatError("empty witness stack")
+    wmap = None
+    for _ in range(items):
+        r.u32()
+        wmap = {}
+        for _ in range(r.u64()):
+            k = r.u32()
+            wmap[k] = r.field()
+    if r.o != len(r.d):
+        raise AcirFormatError("%d trailing bytes in the witness stack" % (len(r.d) - r.o))
+    return wmap
+
+
+def abi_input_row(program, witness_map):
+    """Input wires of the circuit (public first, ABI order) from a solved nargo witness: exactly the row spp_prove_batch takes
+    for the same statement (Prover.toml order of client/proof.helper.ts:34-50)."""
+    row = []
+    for name, ws in program.parameter_witnesses():
+        for w in ws:
+            if w not in witness_map:
+                raise AcirFormatError("witness %d (parameter %s) missing from the witness stack" % (w, name))
+            row.append(witness_map[w] % R)
+    return row
+
+
+def r1cs_rows(circuit):
+    """AssertZero opcodes as R1CS rows (A, B, C) with <A,w> * <B,w> = <C,w>, wires = ACIR witness indices + 1 (wire 0 = one):
+    an opcode qM*w_a*w_b + sum q_i*w_i + c = 0 with ONE product is one row A = qM*w_a, B = w_b, C = -(sum q_i*w_i + c).
+    Opcodes with several products are returned in `wide` (they need helper wires).  How sunspot lowers ACIR to gnark's R1CS."""
+    rows, wide = [], []
+    for i, op in enumerate(circuit.opcodes):
+        if op[0] != "AssertZero":
+            continue
+        e = op[1]
+        neg = [((-c) % R, w + 1) for c, w in e.linear]
+        if e.constant:
+            neg.append(((-e.constant) % R, 0))
+        if len(e.mul_terms) == 0:
+            rows.append(([], [], neg))      # purely linear: 0 * 0 = <C,w>
+        elif len(e.mul_terms) == 1:
+            c, a, b = e.mul_terms[0]
+            rows.append(([(c, a + 1)], [(1, b + 1)], neg))
+        else:
+            wide.append(i)
+    return rows, wide
+
+
+# ---- witness generation for the reference's ACIR (what `nargo execute` does, client/proof.helper.ts:55) ----
+# Grumpkin (Noir's embedded curve): y^2 = x^3 - 17 over BN254 Fr (client/merkle.ts:47-74)
+_GK_GEN = (1, 17631683881184975370165255887551781615748388533673675138860)
+
+
+def _gk_add(a, b):
+    if a is None:
+        return b
+    if b is None:
+        return a
+    if a[0] == b[0]:
+        if (a[1] + b[1]) % R == 0:
+            return None
+        lam = 3 * a[0] * a[0] * pow(2 * a[1], -1, R) % R
+    else:
+        lam = (b[1] - a[1]) * pow(b[0] - a[0], -1, R) % R
+    x = (lam * lam - a[0] - b[0]) % R
+    return (x, (lam * (a[0] - x) - a[1]) % R)
+
+
+def _gk_mul(pt, k):
+    acc = None
+    while k:
+        if k & 1:
+            acc = _gk_add(acc, pt)
+        pt = _gk_add(pt, pt)
+        k >>= 1
+    return acc
+
+
+class UnsatisfiedConstraint(ValueError):
+    def __init__(self, index, what):
+        super().__init__("ACIR opcode %d: %s" % (index, what))
+        self.opcode_index = index
+
+
+def _brillig(fid, args, n_out):
+    """The three unconstrained helper functions of the reference's withdraw circuit, by their semantics (the constraints
+    that follow each call pin them): 0 = (a, b) -> (a // b, a % b) [field -> 128-bit limbs], 1 = x -> 1/x (0 -> 0) [is-zero
+    and != gadgets], 2 = (x, n, radix) -> n little-endian digits [index -> 16 path bits].  Brillig bytecode is not interpreted."""
+    if fid == 0:
+        a, b = args[0], args[1]
+        return [a // b, a % b]
+    if fid == 1:
+        return [pow(args[0], -1, R) if args[0] % R else 0]
+    if fid == 2:
+        x, radix = args[0], args[2]          # (value, number of limbs, radix)
+        out = []
+        for _ in range(n_out):
+            out.append(x % radix)
+            x //= radix
+        return out
+    raise AcirFormatError("Brillig function %d has no host implementation" % fid)
+
+
+def execute(program, input_row):
+    """Solves every witness of the program's main function from the ABI input row (public first): ACVM's loop -- an
+    AssertZero with one unknown witness defines it, with none it is checked; RANGE is checked; MultiScalarMul is the Grumpkin
+    fixed-base multiplication; BrilligCall runs the host helper.  Returns {witness: value}; raises UnsatisfiedConstraint with
+    the opcode index when the inputs do not satisfy the circuit (the `nargo execute` failure of proof.helper.ts:55)."""
+    c = program.main
+    w = {}
+    flat = [x for _, ws in program.parameter_witnesses() for x in ws]
+    if len(flat) != len(input_row):
+        raise ValueError("expected %d inputs" % len(flat))
+    for k, v in zip(flat, input_row):
+        w[k] = int(v) % R
+
+    def value(e):
+        s = e.constant
+        for cf, a, b in e.mul_terms:
+            s += cf * w[a] * w[b]
+        for cf, a in e.linear:
+            s += cf * w[a]
+        return s % R
+
+    for idx, op in enumerate(c.opcodes):
+        kind = op[0]
+        if kind == "AssertZero":
+            e = op[1]
+            unknown = set()
+            for _, a, b in e.mul_terms:
+                unknown.update(x for x in (a, b) if x not in w)
+            unknown.update(a for _, a in e.linear if a not in w)
+            if not unknown:
+                if value(e) != 0:
+                    raise UnsatisfiedConstraint(idx, "assertion failed")
+                continue
+            if len(unknown) != 1:
+                raise AcirFormatError("opcode %d has %d unknown witnesses" % (idx, len(unknown)))
+            u = unknown.pop()
+            coeff, rest = 0, e.constant
+            for cf, a, b in e.mul_terms:
+                if a == u and b == u:
+                    raise AcirFormatError("opcode %d is quadratic in its unknown" % idx)
+                if a == u:
+                    coeff += cf * w[b]
+                elif b == u:
+                    coeff += cf * w[a]
+                else:
+                    rest += cf * w[a] * w[b]
+            for cf, a in e.linear:
+                if a == u:
+                    coeff += cf
+                else:
+                    rest += cf * w[a]
+            coeff %= R
+            if coeff == 0:
+                if rest % R:
+                    raise UnsatisfiedConstraint(idx, "assertion failed")
+                w[u] = 0
+            else:
+                w[u] = (-rest) * pow(coeff, -1, R) % R
+        elif kind == "RANGE":
+            _, (t, v), bits = op
+            val = v if t == "constant" else w[v]
+            if val >> bits:
+                raise UnsatisfiedConstraint(idx, "value does not fit %d bits" % bits)
+        elif kind == "MultiScalarMul":
+            _, points, scalars, predicate, outs = op
+            get = lambda fi: fi[1] if fi[0] == "constant" else w[fi[1]]
+            acc = None
+            for k in range(len(points) // 3):
+                px, py, inf = (get(points[3 * k + i]) for i in range(3))
+                lo, hi = get(scalars[2 * k]), get(scalars[2 * k + 1])
+                if not inf:
+                    acc = _gk_add(acc, _gk_mul((px, py), lo + (hi << 128)))
+            w[outs[0]], w[outs[1]], w[outs[2]] = (0, 0, 1) if acc is None else (acc[0], acc[1], 0)
+        elif kind == "BrilligCall":
+            _, fid, inputs, outputs, predicate = op
+            flat_out = [x for o in outputs for x in ([o[1]] if o[0] == "simple" else o[1])]
+            if predicate is not None and value(predicate) == 0:
+                for x in flat_out:
+                    w[x] = 0
+                continue
+            args = []
+            for i in inputs:
+                if i[0] == "single":
+                    args.append(value(i[1]))
+                elif i[0] == "array":
+                    args.extend(value(x) for x in i[1])
+                else:
+                    raise AcirFormatError("opcode %d: Brillig memory inputs are not supported" % idx)
+            for x, v in zip(flat_out, _brillig(fid, args, len(flat_out))):
+                w[x] = v % R
+    return w

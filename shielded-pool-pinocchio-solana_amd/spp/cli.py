@@ -5,6 +5,10 @@ output-file naming (outputs land next to the circuit file, as sunspot writes the
     python -m spp.cli setup   target/<name>.sppc [--seed HEX32]                                   # -> <name>.pk, <name>.vk
     python -m spp.cli prove   target/<name>.sppc target/<name>.pk Prover.toml                    # -> <name>.proof, <name>.pw
     python -m spp.cli verify  target/<name>.vk target/<name>.proof target/<name>.pw              # exit 0 / 1
+    python -m spp.cli execute target/<name>.json Prover.toml [-o target/<name>.gz]               # `nargo execute`: ACIR witness stack
+    python -m spp.cli prove   target/<name>.json target/<name>.gz target/<name>.sppc target/<name>.pk
+                              # sunspot's own argument order (acir, witness, constraint system, proving key;
+                              # client/proof.helper.ts:58-64): the inputs are taken from the nargo witness file
 
 Reference call sites: noir_circuit/prove_linux.sh:66-87, audit_circuit/prove_audit.sh:53-99,
 scripts/generate_audit.py:659-691, scripts/benchmark_all.py:646-690 (parses the `nbConstraints=` line).
@@ -56,8 +60,10 @@ def main(argv=None):
     sub = ap.add_subparsers(dest="cmd", required=True)
     c = sub.add_parser("compile"); c.add_argument("circuit", choices=["withdraw", "audit"]); c.add_argument("--rlwe-pk"); c.add_argument("-o", "--out", required=True)
     s = sub.add_parser("setup"); s.add_argument("sppc"); s.add_argument("--seed", default=None); s.add_argument("--device", type=int, default=0)
-    p = sub.add_parser("prove"); p.add_argument("sppc"); p.add_argument("pk"); p.add_argument("toml"); p.add_argument("--device", type=int, default=0)
+    p = sub.add_parser("prove"); p.add_argument("files", nargs="+", help="<sppc> <pk> <Prover.toml>  |  <acir.json> <witness.gz> <sppc> <pk>")
+    p.add_argument("--device", type=int, default=0)
     p.add_argument("--window", type=int, default=0)
+    x = sub.add_parser("execute"); x.add_argument("acir"); x.add_argument("toml"); x.add_argument("-o", "--out", default=None)
     v = sub.add_parser("verify"); v.add_argument("vk"); v.add_argument("proof"); v.add_argument("pw")
     a = ap.parse_args(argv)
     if a.cmd == "compile":
@@ -77,9 +83,32 @@ def main(argv=None):
         ctx.setup(a.sppc, seed, base + ".pk", base + ".vk")
         ctx.close()
         return 0
-    if a.cmd == "prove":
-        base = os.path.splitext(a.sppc)[0]
+    if a.cmd == "execute":
+        from . import acir
+        prog = acir.load_program(a.acir)
         _, row = input_vector(parse_prover_toml(open(a.toml).read()))
+        try:
+            w = acir.execute(prog, row)
+        except acir.UnsatisfiedConstraint as e:
+            print("spp execute: %s" % e, file=sys.stderr)
+            return 1
+        out = a.out or os.path.splitext(a.acir)[0] + ".gz"
+        acir.write_witness_stack(out, w)
+        print("[%s] Circuit witness successfully solved" % prog.main.name)
+        print("[%s] Witness saved to %s" % (prog.main.name, out))
+        return 0
+    if a.cmd == "prove":
+        if len(a.files) == 3:
+            sppc, pk, toml = a.files
+            _, row = input_vector(parse_prover_toml(open(toml).read()))
+        elif len(a.files) == 4:
+            from . import acir
+            acir_path, gz, sppc, pk = a.files
+            row = acir.abi_input_row(acir.load_program(acir_path), acir.read_witness_stack(gz))
+        else:
+            ap.error("prove takes <sppc> <pk> <Prover.toml> or <acir.json> <witness.gz> <sppc> <pk>")
+        a.sppc, a.pk = sppc, pk
+        base = os.path.splitext(a.sppc)[0]
         ctx = Context(a.device)
         h = ctx.load_circuit(a.sppc, a.pk, a.window)
         proofs, pws, status = h.prove_batch([row])

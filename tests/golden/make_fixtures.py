@@ -4,7 +4,8 @@
 Run from the repo root:  python tests/golden/make_fixtures.py
 Reads  /root/reference/scripts/generate_audit.py (imported, never copied),
        /root/reference/demo-frontend/public/rlwe/rlwe_pk.json, client/prover-params.toml (data).
-Writes tests/golden/{rlwe_pk.json, rlwe_vectors.json, withdraw_kat.json, pack_kat.json}.
+Writes tests/golden/{rlwe_pk.json, rlwe_vectors.json, withdraw_kat.json, pack_kat.json} and copies the binary artefacts
+reference_{withdraw,audit}.vk, reference_withdraw.ccs, reference_withdraw_acir.json (bytecode + abi, no source text).
 Only inputs and expected outputs are stored -- no reference source text.
 """
 import importlib.util, json, os, random, re, sys
@@ -115,6 +116,22 @@ def main():
     assert len(kat["siblings"]) == 16
     with open(os.path.join(HERE, "withdraw_kat.json"), "w") as f:
         json.dump(kat, f, indent=1)
+    # binary / compiled artefacts the reference holds for the proving path, kept as DATA fixtures:
+    #  * the two gnark-made verifying keys
+    #  * the gnark R1CS container of the withdraw circuit (App. A.4)
+    #  * the compiled ACIR program of the withdraw circuit: bytecode + abi only -- file_map / debug_symbols embed Noir source
+    #    text and are dropped
+    import shutil
+    shutil.copyfile(os.path.join(REF, "noir_circuit", "target", "shielded_pool_verifier.vk"), os.path.join(HERE, "reference_withdraw.vk"))
+    shutil.copyfile(os.path.join(REF, "audit_circuit", "target", "rlwe_audit.vk"), os.path.join(HERE, "reference_audit.vk"))
+    shutil.copyfile(os.path.join(REF, "noir_circuit", "target", "shielded_pool_verifier.ccs"), os.path.join(HERE, "reference_withdraw.ccs"))
+    j = json.load(open(os.path.join(REF, "noir_circuit", "target", "shielded_pool_verifier.json")))
+    out = {k: j[k] for k in ("noir_version", "hash", "abi", "bytecode", "expression_width")}
+    out["_note"] = ("data fixture: the compiled ACIR program of the reference's withdraw circuit (noir_circuit/target/"
+                    "shielded_pool_verifier.json) WITHOUT its file_map / debug_symbols members (those embed Noir source text); "
+                    "made by tests/golden/make_fixtures.py")
+    with open(os.path.join(HERE, "reference_withdraw_acir.json"), "w") as f:
+        json.dump(out, f)
     print("fixtures written")
 
 

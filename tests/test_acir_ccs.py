@@ -1,0 +1,196 @@
+"""the reference's own compiled artefacts of the withdraw circuit, read by the product's host code
+(spp/acir.py, spp/ccs.py) and pinned to the numbers SURVEY App. A.4 / A.5 record for them.
+
+  tests/golden/reference_withdraw_acir.json   bytecode + abi of noir_circuit/target/shielded_pool_verifier.json
+  tests/golden/reference_withdraw.ccs         noir_circuit/target/shielded_pool_verifier.ccs (gnark 0.14 R1CS container)
+Both are data files the reference holds (copied by tests/golden/make_fixtures.py; no source text).
+
+The strongest pin here: the reference's OWN constraint system (6 148 AssertZero opcodes, the Grumpkin black box, 25 range checks)
+is executed on client/prover-params.toml and on fresh notes built by the oracle -- it accepts exactly what the repository's
+R1CS accepts, so the statement proved here is the statement the reference's circuit states."""
+import json
+import os
+import random
+import pytest
+from conftest import GOLDEN
+
+
+@pytest.fixture(scope="module")
+def program():
+    from spp import acir
+    return acir.load_program(os.path.join(GOLDEN, "reference_withdraw_acir.json"))
+
+
+def test_acir_program_matches_the_recorded_facts(program):
+    from spp import acir
+    c = program.main
+    assert program.noir_version.startswith("1.0.0-beta.18")
+    assert (c.name, c.current_witness_index, len(c.opcodes)) == ("main", 23643, 6180)
+    assert c.histogram() == {"AssertZero": 6148, "RANGE": 25, "BrilligCall": 6, "MultiScalarMul": 1}
+    az = [op[1] for op in c.opcodes if op[0] == "AssertZero"]
+    assert sum(len(e.mul_terms) for e in az) == 4688 and sum(len(e.linear) for e in az) == 44714
+    assert sum(1 for e in az if len(e.mul_terms) == 1 and len(e.linear) == 1) == 4552      # Poseidon S-box steps
+    assert sum(1 for e in az if len(e.linear) == 61) == 55                                  # MDS rows
+    ranges = {}
+    for op in c.opcodes:
+        if op[0] == "RANGE":
+            ranges[op[2]] = ranges.get(op[2], 0) + 1
+    assert ranges == {64: 1, 126: 6, 128: 2, 1: 16}
+    assert c.opcodes[0] == ("RANGE", ("witness", 3), 64)                                    # amount: u64
+    msm = [op for op in c.opcodes if op[0] == "MultiScalarMul"][0]
+    assert msm[1] == [("constant", 1), ("constant", 17631683881184975370165255887551781615748388533673675138860), ("constant", 0)]   # Grumpkin G
+    # ABI order = TOML key order of client/proof.helper.ts:34-50; parameters sit on witnesses 0..25, public ones first
+    names = [n for n, _ in program.parameter_witnesses()]
+    assert names == ["root", "nullifier", "recipient", "amount", "wa_commitment", "secret_key", "owner_x", "owner_y", "randomness", "index", "siblings"]
+    assert c.public_parameters == [0, 1, 2, 3, 4] and c.private_parameters == list(range(5, 26)) and c.return_values == []
+    assert program.parameter_witnesses()[-1][1] == list(range(10, 26))
+    rows, wide = acir.r1cs_rows(c)
+    assert len(rows) + len(wide) == 6148 and len(wide) == 51
+
+
+def test_reference_acir_accepts_the_reference_kat_and_refuses_what_main_asserts(program, withdraw_kat):
+    """`nargo execute` on the reference's own inputs, by the host executor: every constraint of the reference's circuit holds
+    for client/prover-params.toml; each assertion of noir_circuit/src/main.nr:38-82 fires on the matching mutation."""
+    from spp import acir
+    from oracle import circuit as C
+    good = C.withdraw_inputs(withdraw_kat)
+    w = acir.execute(program, good)
+    assert len(w) == 6189 and max(w) == 23643           # 5 public + 6184 secret witnesses of the gnark system (App. A.4)
+    assert [w[i] for i in range(26)] == [v % acir.R for v in good]
+    for pos, val in ((0, good[0] + 1), (1, good[1] + 1), (2, 0), (3, 1 << 64), (4, good[4] + 1), (5, good[5] + 1), (6, good[6] + 1),
+                     (8, good[8] + 1), (9, 1), (9, 1 << 16), (12, good[12] + 1)):
+        bad = list(good)
+        bad[pos] = val
+        with pytest.raises(acir.UnsatisfiedConstraint):
+            acir.execute(program, bad)
+    other = list(good); other[2] = good[2] + 1          # the recipient is free (only != 0)
+    acir.execute(program, other)
+
+
+def test_reference_acir_and_repository_r1cs_accept_the_same_statements(program, withdraw_artifacts):
+    """Fresh notes (oracle hashes, pinned by the KAT) in a tree: accepted by the reference's ACIR and by the repository's
+    R1CS; one flipped input each: refused by both."""
+    from spp import acir
+    from oracle import hashes as H, native
+    rng = random.Random(4)
+    tree = H.MerkleTree()
+    notes = []
+    for _ in range(6):
+        sk = rng.randrange(1, 1 << 128)
+        owner = H.fixed_base_scalar_mul(sk)
+        amount, rnd = rng.randrange(1, 1 << 63), rng.randrange(1 << 253)
+        idx = tree.insert(H.poseidon_hash4(owner[0], owner[1], amount, rnd))
+        notes.append((sk, owner, amount, rnd, idx))
+    root = tree.root()
+    p = native.Prover(withdraw_artifacts["sppc"], withdraw_artifacts["pk"])
+    rows = []
+    for sk, owner, amount, rnd, idx in notes:
+        rows.append([root, H.poseidon_hash2(sk, idx), rng.randrange(1, 1 << 240), amount, H.poseidon_hash2(owner[0], owner[1]),
+                     sk, owner[0], owner[1], rnd, idx] + tree.proof(idx))
+    assert native.check_many(p, rows) == [-1] * len(rows)
+    for row in rows:
+        acir.execute(program, row)
+    for k, row in enumerate(rows):
+        bad = list(row)
+        pos = (0, 1, 4, 5, 9, 10 + k)[k]
+        bad[pos] = (bad[pos] + 1) % acir.R
+        assert native.check_many(p, [bad])[0] >= 0
+        with pytest.raises(acir.UnsatisfiedConstraint):
+            acir.execute(program, bad)
+
+
+def test_witness_stack_round_trip_and_input_extraction(program, withdraw_kat, tmp_path):
+    """target/<name>.gz (client/proof.helper.ts:58-66): writer and reader are inverse; the ABI inputs come back out of a
+    full witness in Prover.toml order -- the row spp_prove_batch takes."""
+    from spp import acir
+    from oracle import circuit as C
+    good = C.withdraw_inputs(withdraw_kat)
+    w = acir.execute(program, good)
+    path = str(tmp_path / "shielded_pool_verifier.gz")
+    acir.write_witness_stack(path, w)
+    back = acir.read_witness_stack(path)
+    assert back == w
+    assert acir.abi_input_row(program, back) == [v % acir.R for v in good]
+    del back[7]
+    with pytest.raises(acir.AcirFormatError):
+        acir.abi_input_row(program, back)
+
+
+def test_ccs_container_matches_the_recorded_facts():
+    from spp import ccs
+    c = ccs.load_ccs(os.path.join(GOLDEN, "reference_withdraw.ccs"))
+    assert c.file_size == 576547 and c.header0 == c.file_size - 32 and c.header_opaque == (0, 14, 0)
+    assert (c.levels_len, c.instructions_len, c.calldata_len, c.cbor_len) == (19532, 15396, 394954, 94465)
+    assert c.cbor_offset == 429946 and c.coeff_offset == 524411 and c.trailing == 0
+    m = c.meta
+    assert m["GnarkVersion"] == "0.14.0" and int(m["ScalarField"], 16) == ccs.R and m["Type"] == 1
+    assert (c.n_constraints, c.n_internal, len(c.public), len(c.secret)) == (12452, 6749, 6, 6184)
+    assert c.public == ["1", "root", "nullifier", "recipient", "amount", "wa_commitment"]      # order of withdraw.rs:74-90
+    assert c.secret[0] == "__witness_5" and c.secret[-1] == "__witness_23643"                   # = the ACIR witnesses
+    assert 6 + 6184 + 6749 == 12939 and 12452 <= 1 << 14                                        # wires; FFT domain 2^14
+    ci = m["CommitmentInfo"].value
+    assert len(ci) == 1 and ci[0]["CommitmentIndex"] == 12426 and len(ci[0]["PrivateCommitted"]) == 490      # one BSB22 commitment
+    assert ci[0]["NbPublicCommitted"] == 0 and ci[0]["PublicAndCommitmentCommitted"] == []
+    hints = sorted(v.rsplit("/", 1)[-1] for v in m["MHintsDependencies"].values())
+    assert hints == sorted(["rangecheck.DecomposeHint", "emulated.mulHint", "hints.Randomize", "sw-grumpkin.decompose", "logderivarg.countHint",
+                            "solver.InvZeroHint", "sw-grumpkin.decomposeScalar", "bits.nBits", "cs.Bsb22CommitmentComputePlaceholder"])
+    assert len(c.coefficients_mont) == 1629
+    assert c.coefficients_mont[1] == (1 << 256) % ccs.R                  # entry 1 = R mod r (Montgomery one)
+    assert [ccs.coefficient(c, i) for i in range(5)] == [0, 1, 2, ccs.R - 1, ccs.R - 2]
+    assert all(v < ccs.R for v in c.coefficients_mont)
+    # the secret witnesses of the gnark system are exactly the witnesses the ACIR executor solves
+    from spp import acir
+    prog = acir.load_program(os.path.join(GOLDEN, "reference_withdraw_acir.json"))
+    kat = json.load(open(os.path.join(GOLDEN, "withdraw_kat.json")))
+    from oracle import circuit as C
+    w = acir.execute(prog, C.withdraw_inputs(kat))
+    assert sorted(int(s.split("_")[-1]) for s in c.secret) == sorted(k for k in w if k >= 5)
+
+
+def test_fixtures_equal_the_reference_files():
+    ref = "/root/reference/noir_circuit/target"
+    if not os.path.exists(ref):
+        pytest.skip("reference tree not present on this machine")
+    assert open(os.path.join(ref, "shielded_pool_verifier.ccs"), "rb").read() == open(os.path.join(GOLDEN, "reference_withdraw.ccs"), "rb").read()
+    j = json.load(open(os.path.join(ref, "shielded_pool_verifier.json")))
+    f = json.load(open(os.path.join(GOLDEN, "reference_withdraw_acir.json")))
+    assert j["bytecode"] == f["bytecode"] and j["abi"] == f["abi"] and "file_map" not in f and "debug_symbols" not in f
+
+
+def test_cli_execute_writes_a_nargo_style_witness(tmp_path, withdraw_kat, capsys):
+    """`spp execute` = the `nargo execute` step of proof.helper.ts:55 for the reference's compiled circuit: Prover.toml in,
+    target/<name>.gz out; unsatisfiable inputs exit 1."""
+    from spp import cli, acir
+    from spp.proof_helper import ShieldedPoolInputs, prover_toml
+    k = withdraw_kat
+    inp = ShieldedPoolInputs(**{f: k[f] for f in ("root", "nullifier", "recipient", "amount", "wa_commitment", "secret_key", "owner_x",
+                                                  "owner_y", "randomness", "index", "siblings")})
+    toml = tmp_path / "Prover.toml"
+    toml.write_text(prover_toml(inp))
+    out = tmp_path / "shielded_pool_verifier.gz"
+    assert cli.main(["execute", os.path.join(GOLDEN, "reference_withdraw_acir.json"), str(toml), "-o", str(out)]) == 0
+    assert "successfully solved" in capsys.readouterr().out
+    w = acir.read_witness_stack(str(out))
+    assert len(w) == 6189 and w[3] == k["amount"]
+    bad = tmp_path / "Bad.toml"
+    bad.write_text(prover_toml(inp).replace(k["nullifier"], k["root"]))
+    assert cli.main(["execute", os.path.join(GOLDEN, "reference_withdraw_acir.json"), str(bad), "-o", str(out)]) == 1
+
+
+@pytest.mark.gpu
+def test_cli_prove_from_nargo_files_on_gpu(tmp_path, withdraw_kat, withdraw_artifacts):
+    """sunspot's argument order: `spp prove <acir.json> <witness.gz> <sppc> <pk>` -- the inputs come out of the nargo witness."""
+    import shutil
+    import spp
+    from spp import cli, acir
+    from oracle import circuit as C, groth16
+    prog = acir.load_program(os.path.join(GOLDEN, "reference_withdraw_acir.json"))
+    gz = str(tmp_path / "w.gz")
+    acir.write_witness_stack(gz, acir.execute(prog, C.withdraw_inputs(withdraw_kat)))
+    sppc = str(tmp_path / "shielded_pool_verifier.sppc")
+    shutil.copy(withdraw_artifacts["sppc"], sppc)
+    assert cli.main(["prove", os.path.join(GOLDEN, "reference_withdraw_acir.json"), gz, sppc, withdraw_artifacts["pk"], "--window", "6"]) == 0
+    proof = open(str(tmp_path / "shielded_pool_verifier.proof"), "rb").read()
+    pw = open(str(tmp_path / "shielded_pool_verifier.pw"), "rb").read()
+    assert len(proof) == 388 and pw == groth16.public_witness_bytes(C.withdraw_inputs(withdraw_kat)[:5])
+    assert spp.verify(open(withdraw_artifacts["vk"], "rb").read(), proof, pw)
