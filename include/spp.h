@@ -163,6 +163,20 @@ int spp_merkle_root_batch(spp_ctx* ctx, size_t count, uint32_t depth, const uint
  * nodes = default hashes (:150-156); siblings_out = n_queries * depth * 32 B */
 int spp_merkle_build(spp_ctx* ctx, size_t n_leaves, uint32_t depth, const uint8_t* leaves, size_t n_queries,
                      const uint64_t* query_indices, uint8_t* siblings_out, uint8_t* root_out);
+/* The same tree kept RESIDENT in HBM and updated incrementally: insert() appends leaves and recomputes only the
+ * touched paths -- O(count + depth) Poseidon hashes per call instead of the O(2^depth) recomputation of every getRoot() /
+ * getProof() in client/merkle.ts:165-221; getRoot is one read, getProof `depth` reads per query.  Leaves must be canonical
+ * field elements (32 B big-endian).  Calls on one tree are serialised with the other calls on its context. */
+typedef struct spp_merkle_tree spp_merkle_tree;
+int spp_merkle_tree_new(spp_ctx* ctx, uint32_t depth, spp_merkle_tree** out);
+void spp_merkle_tree_free(spp_merkle_tree* t);
+uint64_t spp_merkle_tree_size(const spp_merkle_tree* t);
+/* ShieldedPoolMerkleTree.insert (client/merkle.ts:158-163) for `count` leaves; *first_index (optional) = index of the first */
+int spp_merkle_tree_insert(spp_merkle_tree* t, size_t count, const uint8_t* leaves, uint64_t* first_index);
+int spp_merkle_tree_root(spp_merkle_tree* t, uint8_t root[32]);
+/* getProof for n leaf indices (any index below 2^depth, inserted or not): siblings_out = n * depth * 32 B */
+int spp_merkle_tree_proofs(spp_merkle_tree* t, size_t n, const uint64_t* indices, uint8_t* siblings_out);
+
 /* generateIdentityKeypair's sk * G on Grumpkin (client/merkle.ts:98-113; scalar = the canonical field element,
  * as noir_circuit/src/main.nr:54-59): sk count * 32 B -> (x, y) count * 64 B */
 int spp_grumpkin_keygen_batch(spp_ctx* ctx, size_t count, const uint8_t* sk, uint8_t* xy);

@@ -264,6 +264,8 @@ class MerkleTree:
         return len(self.leaves) - 1
 
     def _levels(self):
+        if getattr(self, "_cache", None) is not None and self._cache[0] == len(self.leaves):
+            return self._cache[1]               # same recomputation as client/merkle.ts, memoised until the next insert
         levels = [list(self.leaves)]
         for i in range(self.depth):
             cur = levels[-1]
@@ -273,6 +275,7 @@ class MerkleTree:
                 right = cur[j + 1] if j + 1 < len(cur) else self.defaults[i]
                 nxt.append(poseidon_hash2(left, right))
             levels.append(nxt)
+        self._cache = (len(self.leaves), levels)
         return levels
 
     def root(self):

@@ -73,6 +73,17 @@ void launch_poseidon_hash(hipStream_t st, HashConsts hc, const uint8_t* in_be, u
 void launch_merkle_path(hipStream_t st, HashConsts hc, const uint8_t* leaf_be, const uint64_t* index, const uint8_t* siblings_be,
                         uint32_t depth, uint8_t* root_be, uint32_t count);
 void launch_merkle_level(hipStream_t st, HashConsts hc, const Fr* children, uint32_t n_children, Fr dflt, Fr* parents, uint32_t n_parents);
+// incremental Poseidon-Merkle tree resident in HBM (spp_merkle_tree_*): level[l] holds count[l] = ceil(n_leaves / 2^l) nodes
+struct MerkleTreeDev {
+  Fr* level[33];
+  uint64_t count[33];
+  Fr dflt[33];
+  uint32_t depth;
+};
+void launch_merkle_defaults(hipStream_t st, HashConsts hc, Fr* out, uint32_t depth);
+void launch_merkle_update(hipStream_t st, HashConsts hc, const Fr* children, uint64_t n_children, const Fr* dflt_level, Fr* parents,
+                          uint64_t first, uint32_t n);
+void launch_merkle_gather(hipStream_t st, const MerkleTreeDev* t, uint32_t depth, const uint64_t* indices, uint32_t nq, uint8_t* out_be);
 void launch_fr_from_be(hipStream_t st, const uint8_t* in, Fr* out, uint32_t n);
 void launch_fr_to_be(hipStream_t st, const Fr* in, uint8_t* out, uint32_t n);
 void launch_grumpkin_keygen(hipStream_t st, const GkAffine* table, const uint8_t* sk_be, uint8_t* xy_be, uint32_t count);

@@ -289,6 +289,51 @@ __global__ void __launch_bounds__(64) k_merkle_level(HashConsts hc, const Fr* __
 void launch_merkle_level(hipStream_t st, HashConsts hc, const Fr* children, uint32_t n_children, Fr dflt, Fr* parents, uint32_t n_parents) {
   if (n_parents) hipLaunchKernelGGL(k_merkle_level, dim3((n_parents + 63) / 64), dim3(64), 0, st, hc, children, n_children, dflt, parents, n_parents);
 }
+// ---- incremental tree (spp_merkle_tree_*): levels stay resident in HBM; an append touches O(count + depth) nodes ----
+// default (empty-subtree) hashes: d_0 = 0, d_{l+1} = H(d_l, d_l)   (client/merkle.ts:150-156)
+__global__ void __launch_bounds__(64) k_merkle_defaults(HashConsts hc, Fr* __restrict__ out, uint32_t depth) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  Fr d = Fr::zero();
+  out[0] = d;
+  for (uint32_t l = 0; l < depth; l++) {
+    d = poseidon_hash2(hc, d, d);
+    out[l + 1] = d;
+  }
+}
+// parents [first, first + n) of one level, recomputed from its children; children at or beyond n_children are the level default
+__global__ void __launch_bounds__(64) k_merkle_update(HashConsts hc, const Fr* __restrict__ children, uint64_t n_children,
+                                                      const Fr* __restrict__ dflt_level, Fr* __restrict__ parents, uint64_t first, uint32_t n) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  const uint64_t j = first + g;
+  const Fr d = *dflt_level;
+  const Fr l = 2 * j < n_children ? children[2 * j] : d;
+  const Fr r = 2 * j + 1 < n_children ? children[2 * j + 1] : d;
+  parents[j] = poseidon_hash2(hc, l, r);
+}
+// getProof (client/merkle.ts:198-221) without any hashing: sibling of level l = stored node or the level default
+__global__ void __launch_bounds__(64) k_merkle_gather(const MerkleTreeDev* __restrict__ t, const uint64_t* __restrict__ indices, uint32_t nq,
+                                                      uint8_t* __restrict__ out_be) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t depth = t->depth;
+  if (g >= nq * depth) return;
+  const uint32_t q = g / depth, l = g % depth;
+  const uint64_t sib = (indices[q] >> l) ^ 1;
+  const Fr v = sib < t->count[l] ? t->level[l][sib] : t->dflt[l];
+  store_be(out_be + ((size_t)q * depth + l) * 32, v);
+}
+void launch_merkle_defaults(hipStream_t st, HashConsts hc, Fr* out, uint32_t depth) {
+  hipLaunchKernelGGL(k_merkle_defaults, dim3(1), dim3(64), 0, st, hc, out, depth);
+}
+void launch_merkle_update(hipStream_t st, HashConsts hc, const Fr* children, uint64_t n_children, const Fr* dflt_level, Fr* parents,
+                          uint64_t first, uint32_t n) {
+  if (n) hipLaunchKernelGGL(k_merkle_update, dim3((n + 63) / 64), dim3(64), 0, st, hc, children, n_children, dflt_level, parents, first, n);
+}
+void launch_merkle_gather(hipStream_t st, const MerkleTreeDev* t, uint32_t depth, const uint64_t* indices, uint32_t nq, uint8_t* out_be) {
+  const uint32_t n = nq * depth;
+  if (n) hipLaunchKernelGGL(k_merkle_gather, dim3((n + 63) / 64), dim3(64), 0, st, t, indices, nq, out_be);
+}
+
 __global__ void __launch_bounds__(256) k_fr_from_be(const uint8_t* __restrict__ in, Fr* __restrict__ out, uint32_t n) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g < n) out[g] = load_be(in + (size_t)g * 32);

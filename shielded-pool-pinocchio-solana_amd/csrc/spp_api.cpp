@@ -1,149 +1,11 @@
-// libspp C ABI (include/spp.h): host orchestration of the HIP proving pipeline.
-// Everything heavy runs on the GPU; the host parses containers, derives one-time constants and enqueues
-// kernels on one stream per context.  There is deliberately no CPU implementation of the hot path here.
-#include "../../include/spp.h"
+// libspp C ABI (include/spp.h), core: contexts, circuit loading (window tables in HBM), the batched proving pipeline and the
+// trusted setup.  Everything heavy runs on the GPU; the host parses containers, derives one-time constants and enqueues
+// kernels.  There is deliberately no CPU implementation of the hot path here.
+#include "spp_internal.hpp"
 
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <mutex>
-#include <string>
-#include <vector>
-
-#include "circuit.hpp"
-#include "kernels.hpp"
-#include "sha256.hpp"
-#include "f29.hpp"
-#include "pairing.hpp"
-#include "pairing_fast_host.hpp"
-
-using namespace spp;
-
-// -----------------------------------------------------------------------------------------------------
-// errors
-// -----------------------------------------------------------------------------------------------------
-static thread_local char g_err[512] = "";
-static int fail(int code, const char* fmt, ...) {
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(g_err, sizeof g_err, fmt, ap);
-  va_end(ap);
-  return code;
-}
-#define HIP_TRY(expr)                                                                          \
-  do {                                                                                         \
-    hipError_t _e = (expr);                                                                    \
-    if (_e != hipSuccess) return fail(SPP_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e));     \
-  } while (0)
-
-extern "C" const char* spp_last_error(void) { return g_err; }
-extern "C" const char* spp_version(void) { return "libspp 0.1 (gfx950)"; }
-
-// -----------------------------------------------------------------------------------------------------
-// host helpers
-// -----------------------------------------------------------------------------------------------------
-static Fr fr_pow_limbs(const Fr& base, const uint32_t e[8]) {
-  Fr acc = Fr::one(), b = base;
-  for (int w = 0; w < 8; w++)
-    for (int i = 0; i < 32; i++) {
-      if ((e[w] >> i) & 1) acc = acc * b;
-      b = b.sqr();
-    }
-  return acc;
-}
-static Fr fr_root_of_unity(uint32_t logn) {
-  uint32_t e[8];
-  for (int i = 0; i < 8; i++) e[i] = FrParams::MOD(i);
-  e[0] -= 1;
-  for (uint32_t s = 0; s < logn; s++) {
-    for (int i = 0; i < 7; i++) e[i] = (e[i] >> 1) | (e[i + 1] << 31);
-    e[7] >>= 1;
-  }
-  return fr_pow_limbs(Fr::from_u64(5), e);
-}
-static uint32_t bitrev(uint32_t v, uint32_t bits) {
-  uint32_t r = 0;
-  for (uint32_t i = 0; i < bits; i++) r |= ((v >> i) & 1) << (bits - 1 - i);
-  return r;
-}
-static G1Affine g1_from_raw(const uint8_t* b) {
-  bool z = true;
-  for (int i = 0; i < 64; i++) z &= b[i] == 0;
-  if (z) return G1Affine::infinity();
-  return {Fq::from_bytes_be(b), Fq::from_bytes_be(b + 32)};
-}
-static G2Affine g2_from_raw(const uint8_t* b) {
-  bool z = true;
-  for (int i = 0; i < 128; i++) z &= b[i] == 0;
-  if (z) return G2Affine::infinity();
-  G2Affine p;
-  p.x.c1 = Fq::from_bytes_be(b);
-  p.x.c0 = Fq::from_bytes_be(b + 32);
-  p.y.c1 = Fq::from_bytes_be(b + 64);
-  p.y.c0 = Fq::from_bytes_be(b + 96);
-  return p;
-}
-static void g1_to_raw(const G1Affine& p, uint8_t* b) {
-  if (p.is_inf()) { memset(b, 0, 64); return; }
-  p.x.to_bytes_be(b);
-  p.y.to_bytes_be(b + 32);
-}
-static void g2_to_raw(const G2Affine& p, uint8_t* b) {
-  if (p.is_inf()) { memset(b, 0, 128); return; }
-  p.x.c1.to_bytes_be(b);
-  p.x.c0.to_bytes_be(b + 32);
-  p.y.c1.to_bytes_be(b + 64);
-  p.y.c0.to_bytes_be(b + 96);
-}
-template <class F>
-static Affine<F> host_add(const Affine<F>& a, const Affine<F>& b) {
-  XYZZ<F> x = XYZZ<F>::from_affine(a);
-  x.madd(b);
-  return x.to_affine();
-}
-static bool read_file(const char* path, std::vector<uint8_t>& out) {
-  FILE* f = fopen(path, "rb");
-  if (!f) return false;
-  fseek(f, 0, SEEK_END);
-  long sz = ftell(f);
-  fseek(f, 0, SEEK_SET);
-  out.resize((size_t)sz);
-  bool ok = fread(out.data(), 1, out.size(), f) == out.size();
-  fclose(f);
-  return ok;
-}
-
-template <class T>
-static hipError_t dev_upload(T** dst, const std::vector<T>& src) {
-  *dst = nullptr;
-  size_t bytes = sizeof(T) * std::max<size_t>(src.size(), 1);
-  hipError_t e = hipMalloc((void**)dst, bytes);
-  if (e != hipSuccess) return e;
-  if (!src.empty()) e = hipMemcpy(*dst, src.data(), sizeof(T) * src.size(), hipMemcpyHostToDevice);
-  return e;
-}
-
-// -----------------------------------------------------------------------------------------------------
-// context / circuit objects
-// -----------------------------------------------------------------------------------------------------
-struct spp_ctx {
-  int device;
-  hipStream_t stream;        // setup / table construction
-  hipStream_t pstream[2];    // proving: consecutive batches alternate, so the (latency-bound, few-wave) witness
-                             // solver of batch k+1 overlaps the MSMs of batch k
-  std::mutex mu;
-  // lazily created constants of the stand-alone witness kernels
-  bool consts_ready = false;
-  HashConsts hc{};
-  GkAffine* gk_table = nullptr;
-  bool rlwe_ready = false;
-  RlweDev rlwe{};              // NTT tables of the RLWE witness kernel (rlwe_ntt.hpp)
-  std::vector<void*> owned;
-};
+thread_local char g_spp_err[512] = "";
+extern "C" const char* spp_last_error(void) { return g_spp_err; }
+extern "C" const char* spp_version(void) { return "libspp 0.2 (gfx950)"; }
 
 template <class F>
 struct MsmSet {
@@ -278,22 +140,17 @@ static int build_table(spp_circuit* c, const std::vector<Affine<F>>& pts, uint32
   size_t chunk = std::max<size_t>(64, ((temp_budget / per_row) / 64) * 64);
   chunk = std::min(chunk, (size_t)65536);   // larger launches only add TLB misses (the d-stride is chunk * 128 B)
   chunk = std::min(chunk, rows_total);
-  Affine<F>* d_bases;
-  XYZZ<F>* tmp;
-  F* tmp_pre;
-  HIP_TRY(hipMalloc((void**)&d_bases, N * sizeof(Affine<F>)));
-  HIP_TRY(hipMemcpy(d_bases, pts.data(), N * sizeof(Affine<F>), hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc((void**)&tmp, chunk * E * sizeof(XYZZ<F>)));
-  HIP_TRY(hipMalloc((void**)&tmp_pre, chunk * E * sizeof(F)));
+  DevBuf d_bases, tmp, tmp_pre;   // released on every return path
+  HIP_TRY(d_bases.alloc(N * sizeof(Affine<F>)));
+  HIP_TRY(hipMemcpy(d_bases.p, pts.data(), N * sizeof(Affine<F>), hipMemcpyHostToDevice));
+  HIP_TRY(tmp.alloc(chunk * E * sizeof(XYZZ<F>)));
+  HIP_TRY(tmp_pre.alloc(chunk * E * sizeof(F)));
   for (size_t r0 = 0; r0 < rows_total; r0 += chunk) {
     uint32_t cnt = (uint32_t)std::min(chunk, rows_total - r0);
-    launch_build_table<F>(st, d_bases, (uint32_t)N, cbits, (uint32_t)r0, cnt, table, tmp, tmp_pre);
+    launch_build_table<F>(st, d_bases.as<Affine<F>>(), (uint32_t)N, cbits, (uint32_t)r0, cnt, table, tmp.as<XYZZ<F>>(), tmp_pre.as<F>());
   }
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipGetLastError());
-  hipFree(d_bases);
-  hipFree(tmp);
-  hipFree(tmp_pre);
   return 0;
 }
 static size_t table_temp_budget() {
@@ -1203,36 +1060,27 @@ extern "C" int spp_setup(spp_ctx* ctx, const char* circuit_path, const uint8_t s
   g2.x.c1 = fq_dec("11559732032986387107991004021392285783925812861821192530917403151452391805634");
   g2.y.c0 = fq_dec("8495653923123431417604973247489272438418190587263600148770280649306958101930");
   g2.y.c1 = fq_dec("4082367875863433681332203403145435568316851327593401208105741076214120093531");
-  G1Affine *d_g1, *t1, *o1;
-  G2Affine *d_g2, *t2, *o2;
-  G1XYZZ* tmp1;
-  G2XYZZ* tmp2;
-  Fq* pre1;
-  Fq2* pre2;
-  Fr *d_s1, *d_s2;
-  HIP_TRY(hipMalloc((void**)&d_g1, sizeof g1)); HIP_TRY(hipMemcpy(d_g1, &g1, sizeof g1, hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc((void**)&d_g2, sizeof g2)); HIP_TRY(hipMemcpy(d_g2, &g2, sizeof g2, hipMemcpyHostToDevice));
+  DevBuf d_g1, d_g2, t1, t2, tmp1, tmp2, pre1, pre2, d_s1, d_s2, o1, o2;   // released on every return path
+  HIP_TRY(d_g1.alloc(sizeof g1)); HIP_TRY(hipMemcpy(d_g1.p, &g1, sizeof g1, hipMemcpyHostToDevice));
+  HIP_TRY(d_g2.alloc(sizeof g2)); HIP_TRY(hipMemcpy(d_g2.p, &g2, sizeof g2, hipMemcpyHostToDevice));
   const size_t ge = msm_table_elems(1, cb), gr = ((size_t)Wn + 63) / 64 * 64;
-  HIP_TRY(hipMalloc((void**)&t1, sizeof(G1Affine) * ge)); HIP_TRY(hipMalloc((void**)&t2, sizeof(G2Affine) * ge));
-  HIP_TRY(hipMalloc((void**)&tmp1, sizeof(G1XYZZ) * gr * E)); HIP_TRY(hipMalloc((void**)&tmp2, sizeof(G2XYZZ) * gr * E));
-  HIP_TRY(hipMalloc((void**)&pre1, sizeof(Fq) * gr * E)); HIP_TRY(hipMalloc((void**)&pre2, sizeof(Fq2) * gr * E));
-  HIP_TRY(hipMalloc((void**)&d_s1, sizeof(Fr) * s1.size())); HIP_TRY(hipMalloc((void**)&d_s2, sizeof(Fr) * s2.size()));
-  HIP_TRY(hipMalloc((void**)&o1, sizeof(G1Affine) * s1.size())); HIP_TRY(hipMalloc((void**)&o2, sizeof(G2Affine) * s2.size()));
-  HIP_TRY(hipMemcpyAsync(d_s1, s1.data(), sizeof(Fr) * s1.size(), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(d_s2, s2.data(), sizeof(Fr) * s2.size(), hipMemcpyHostToDevice, st));
-  launch_build_table<Fq>(st, d_g1, 1, cb, 0, (uint32_t)gr, t1, tmp1, pre1);
-  launch_build_table<Fq2>(st, d_g2, 1, cb, 0, (uint32_t)gr, t2, tmp2, pre2);
-  launch_fixed_base_mul<Fq>(st, t1, cb, d_s1, (uint32_t)s1.size(), o1, nullptr);
-  launch_fixed_base_mul<Fq2>(st, t2, cb, d_s2, (uint32_t)s2.size(), o2, nullptr);
+  HIP_TRY(t1.alloc(sizeof(G1Affine) * ge)); HIP_TRY(t2.alloc(sizeof(G2Affine) * ge));
+  HIP_TRY(tmp1.alloc(sizeof(G1XYZZ) * gr * E)); HIP_TRY(tmp2.alloc(sizeof(G2XYZZ) * gr * E));
+  HIP_TRY(pre1.alloc(sizeof(Fq) * gr * E)); HIP_TRY(pre2.alloc(sizeof(Fq2) * gr * E));
+  HIP_TRY(d_s1.alloc(sizeof(Fr) * s1.size())); HIP_TRY(d_s2.alloc(sizeof(Fr) * s2.size()));
+  HIP_TRY(o1.alloc(sizeof(G1Affine) * s1.size())); HIP_TRY(o2.alloc(sizeof(G2Affine) * s2.size()));
+  HIP_TRY(hipMemcpyAsync(d_s1.p, s1.data(), sizeof(Fr) * s1.size(), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_s2.p, s2.data(), sizeof(Fr) * s2.size(), hipMemcpyHostToDevice, st));
+  launch_build_table<Fq>(st, d_g1.as<G1Affine>(), 1, cb, 0, (uint32_t)gr, t1.as<G1Affine>(), tmp1.as<G1XYZZ>(), pre1.as<Fq>());
+  launch_build_table<Fq2>(st, d_g2.as<G2Affine>(), 1, cb, 0, (uint32_t)gr, t2.as<G2Affine>(), tmp2.as<G2XYZZ>(), pre2.as<Fq2>());
+  launch_fixed_base_mul<Fq>(st, t1.as<G1Affine>(), cb, d_s1.as<Fr>(), (uint32_t)s1.size(), o1.as<G1Affine>(), nullptr);
+  launch_fixed_base_mul<Fq2>(st, t2.as<G2Affine>(), cb, d_s2.as<Fr>(), (uint32_t)s2.size(), o2.as<G2Affine>(), nullptr);
   std::vector<G1Affine> p1(s1.size());
   std::vector<G2Affine> p2(s2.size());
-  HIP_TRY(hipMemcpyAsync(p1.data(), o1, sizeof(G1Affine) * p1.size(), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(p2.data(), o2, sizeof(G2Affine) * p2.size(), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(p1.data(), o1.p, sizeof(G1Affine) * p1.size(), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(p2.data(), o2.p, sizeof(G2Affine) * p2.size(), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipGetLastError());
-  for (void* q : {(void*)d_g1, (void*)d_g2, (void*)t1, (void*)t2, (void*)tmp1, (void*)tmp2, (void*)pre1, (void*)pre2, (void*)d_s1,
-                  (void*)d_s2, (void*)o1, (void*)o2})
-    hipFree(q);
 
   const G1Affine* pA = p1.data();
   const G1Affine* pB1 = pA + W;
@@ -1286,39 +1134,8 @@ extern "C" int spp_setup(spp_ctx* ctx, const char* circuit_path, const uint8_t s
 }
 
 // -----------------------------------------------------------------------------------------------------
-// micro-benchmark / unit entry points
+// table-based MSM over caller-supplied bases (unit entry point; uses the table builder above)
 // -----------------------------------------------------------------------------------------------------
-extern "C" int spp_ntt_fr(spp_ctx* ctx, uint8_t* data, uint32_t logn, int inverse) {
-  if (!ctx || !data || logn == 0 || logn > 24) return fail(SPP_ERR_BAD_INPUT, "bad argument");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_TRY(hipSetDevice(ctx->device));
-  const uint32_t n = 1u << logn;
-  Fr w = fr_root_of_unity(logn);
-  if (inverse) w = w.inv();
-  std::vector<Fr> tw(n / 2 ? n / 2 : 1), host(n);
-  Fr a = Fr::one();
-  for (uint32_t k = 0; k < n / 2; k++) { tw[k] = a; a = a * w; }
-  for (uint32_t i = 0; i < n; i++) host[i] = Fr::from_bytes_be(data + 32 * (size_t)i);
-  Fr *d_tw, *d_x;
-  HIP_TRY(hipMalloc((void**)&d_tw, sizeof(Fr) * tw.size()));
-  HIP_TRY(hipMalloc((void**)&d_x, sizeof(Fr) * n));
-  HIP_TRY(hipMemcpy(d_tw, tw.data(), sizeof(Fr) * tw.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_x, host.data(), sizeof(Fr) * n, hipMemcpyHostToDevice));
-  launch_ntt(ctx->stream, d_x, logn, 1, d_tw, true, 1, 0);   // DIF: natural in, bit-reversed out
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpy(host.data(), d_x, sizeof(Fr) * n, hipMemcpyDeviceToHost));
-  hipFree(d_tw);
-  hipFree(d_x);
-  Fr ninv = inverse ? Fr::from_u64(n).inv() : Fr::one();
-  for (uint32_t pos = 0; pos < n; pos++) {
-    Fr v = host[pos];
-    if (inverse) v = v * ninv;
-    v.to_bytes_be(data + 32 * (size_t)bitrev(pos, logn));
-  }
-  return SPP_OK;
-}
-
 extern "C" int spp_msm_g1(spp_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, int window_bits, uint8_t out[64]) {
   if (!ctx || !out || (n && (!bases || !scalars))) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
   if (window_bits == 0) window_bits = 8;
@@ -1362,688 +1179,5 @@ extern "C" int spp_msm_g1(spp_ctx* ctx, const uint8_t* bases, const uint8_t* sca
   if (d_out) hipFree(d_out);
   if (e) return e;
   g1_to_raw(res.to_affine(), out);
-  return SPP_OK;
-}
-
-// -----------------------------------------------------------------------------------------------------
-// stand-alone witness-input kernels
-// -----------------------------------------------------------------------------------------------------
-template <class T>
-static int ctx_upload(spp_ctx* ctx, T** dst, const std::vector<T>& src) {
-  HIP_TRY(dev_upload(dst, src));
-  ctx->owned.push_back((void*)*dst);
-  return 0;
-}
-static int ensure_ctx_consts(spp_ctx* ctx) {
-  if (ctx->consts_ready) return 0;
-  auto flat = [](const PoseidonParams& pp) {
-    std::vector<Fr> m;
-    for (auto& row : pp.mds)
-      for (auto& v : row) m.push_back(v);
-    return m;
-  };
-  const PoseidonParams& p3 = poseidon_params(3);
-  const PoseidonParams& p5 = poseidon_params(5);
-  const Poseidon2Params& p2 = poseidon2_params();
-  std::vector<Fr> mu(p2.mu, p2.mu + 4);
-  Fr *a, *b, *c, *d, *f, *g;
-  int e;
-  auto canon = [](std::vector<Fr> v) {
-    for (auto& x : v) x = x.canonical();
-    return v;
-  };
-  auto flat29 = [](const PoseidonParams& pp) {
-    std::vector<uint32_t> m;
-    for (auto& row : pp.mds)
-      for (auto& v : row) {
-        const F29<FrParams> x = F29<FrParams>::from_fp(v);
-        for (int k = 0; k < 9; k++) m.push_back(x.l[k]);
-      }
-    return m;
-  };
-  uint32_t *m3, *m5;
-  if ((e = ctx_upload(ctx, &a, canon(p3.rc))) || (e = ctx_upload(ctx, &b, flat(p3))) || (e = ctx_upload(ctx, &c, canon(p5.rc))) ||
-      (e = ctx_upload(ctx, &d, flat(p5))) || (e = ctx_upload(ctx, &f, p2.rc)) || (e = ctx_upload(ctx, &g, mu)) ||
-      (e = ctx_upload(ctx, &m3, flat29(p3))) || (e = ctx_upload(ctx, &m5, flat29(p5))))
-    return e;
-  ctx->hc = HashConsts{a, b, c, d, f, g, m3, m5};
-  // Grumpkin window table T[j][d] = (d+1) * 16^j * G, j < 64, d < 16
-  std::vector<GkAffine> tab(64 * 16);
-  GkXYZZ base = GkXYZZ::from_affine(grumpkin_generator());
-  for (int j = 0; j < 64; j++) {
-    GkAffine ba = base.to_affine();
-    GkXYZZ run = base;
-    for (int dd = 0; dd < 16; dd++) {
-      tab[j * 16 + dd] = run.to_affine();
-      run.madd(ba);
-    }
-    base = GkXYZZ::from_affine(tab[j * 16 + 15]);
-  }
-  if ((e = ctx_upload(ctx, &ctx->gk_table, tab))) return e;
-  ctx->consts_ready = true;
-  return 0;
-}
-
-namespace {
-// RAII device buffer for the host-pointer convenience entry points
-struct DevBuf {
-  void* p = nullptr;
-  ~DevBuf() { if (p) hipFree(p); }
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
-  template <class T> T* as() { return (T*)p; }
-};
-}  // namespace
-#define UP(buf, src, bytes)                                                              \
-  do {                                                                                    \
-    HIP_TRY(buf.alloc(bytes));                                                            \
-    if (bytes) HIP_TRY(hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, st));      \
-  } while (0)
-
-// twiddle / twist tables of the RLWE NTT kernel (32 KB) + the scratch that receives the transformed public key
-static int ensure_rlwe(spp_ctx* ctx) {
-  if (ctx->rlwe_ready) return 0;
-  static RnHostTables h;   // 33 KB: not on the stack
-  rn_build_tables(h);
-  RlweDev& rd = ctx->rlwe;
-  int e;
-  for (int k = 0; k < 2; k++) {
-    rd.tb.f[k] = h.f[k];
-    rd.pk_scale[k] = h.pk_scale[k];
-    int32_t *w0, *w1, *ps, *ips;
-    if ((e = ctx_upload(ctx, &w0, std::vector<int32_t>(h.w[k][0], h.w[k][0] + 1024))) ||
-        (e = ctx_upload(ctx, &w1, std::vector<int32_t>(h.w[k][1], h.w[k][1] + 1024))) ||
-        (e = ctx_upload(ctx, &ps, std::vector<int32_t>(h.psi[k], h.psi[k] + 1024))) ||
-        (e = ctx_upload(ctx, &ips, std::vector<int32_t>(h.ipsi[k], h.ipsi[k] + 1024))))
-      return e;
-    rd.tb.w[k][0] = w0; rd.tb.w[k][1] = w1; rd.tb.psi[k] = ps; rd.tb.ipsi[k] = ips;
-
-  }
-  void* p = nullptr;
-  HIP_TRY(hipMalloc(&p, sizeof(RlwePkDev)));
-  ctx->owned.push_back(p);
-  rd.pk = (RlwePkDev*)p;
-  ctx->rlwe_ready = true;
-  return 0;
-}
-
-extern "C" int spp_rlwe_witness_batch(spp_ctx* ctx, const uint32_t* pk_a, const uint32_t* pk_b, size_t count, const int8_t* r,
-                                      const int8_t* e1, const int8_t* e2, const uint8_t* msg, uint32_t* c0, uint32_t* c1, int32_t* k0,
-                                      int32_t* k1, uint8_t* packed_be) {
-  if (!ctx || !pk_a || !pk_b || !r || !e1 || !e2 || !msg || !c0 || !c1 || !k0 || !k1) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
-  if (count == 0) return SPP_OK;
-  for (int i = 0; i < 1024; i++)
-    if (pk_a[i] >= 167772161u || pk_b[i] >= 167772161u) return fail(SPP_ERR_BAD_INPUT, "public key coefficient not in [0, q)");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t st = ctx->stream;
-  if (int e = ensure_rlwe(ctx)) return e;
-  DevBuf da, db, dr, de1, de2, dm, dc0, dc1, dk0, dk1, dp;
-  UP(da, pk_a, 4096); UP(db, pk_b, 4096);
-  UP(dr, r, count * 1024); UP(de1, e1, count * 64); UP(de2, e2, count * 1024); UP(dm, msg, count * 64);
-  HIP_TRY(dc0.alloc(count * 64 * 4)); HIP_TRY(dc1.alloc(count * 1024 * 4)); HIP_TRY(dk0.alloc(count * 64 * 4)); HIP_TRY(dk1.alloc(count * 1024 * 4));
-  if (packed_be) HIP_TRY(dp.alloc(count * 157 * 32));
-  launch_rlwe_witness(st, ctx->rlwe, da.as<uint32_t>(), db.as<uint32_t>(), dr.as<int8_t>(), de1.as<int8_t>(), de2.as<int8_t>(), dm.as<uint8_t>(),
-                      dc0.as<uint32_t>(), dc1.as<uint32_t>(), dk0.as<int32_t>(), dk1.as<int32_t>(), packed_be ? dp.as<uint8_t>() : nullptr,
-                      (uint32_t)count);
-  HIP_TRY(hipMemcpyAsync(c0, dc0.p, count * 64 * 4, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(c1, dc1.p, count * 1024 * 4, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(k0, dk0.p, count * 64 * 4, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(k1, dk1.p, count * 1024 * 4, hipMemcpyDeviceToHost, st));
-  if (packed_be) HIP_TRY(hipMemcpyAsync(packed_be, dp.p, count * 157 * 32, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  HIP_TRY(hipGetLastError());
-  return SPP_OK;
-}
-// device-resident form (micro-benchmark: BASELINE.json configs[3]); all pointers are device pointers
-extern "C" int spp_rlwe_witness_batch_device(spp_ctx* ctx, const void* d_pk_a, const void* d_pk_b, size_t count, const void* d_r,
-                                             const void* d_e1, const void* d_e2, const void* d_msg, void* d_c0, void* d_c1, void* d_k0,
-                                             void* d_k1, void* d_packed_be) {
-  if (!ctx) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_TRY(hipSetDevice(ctx->device));
-  if (int e = ensure_rlwe(ctx)) return e;
-  launch_rlwe_witness(ctx->stream, ctx->rlwe, (const uint32_t*)d_pk_a, (const uint32_t*)d_pk_b, (const int8_t*)d_r, (const int8_t*)d_e1,
-                      (const int8_t*)d_e2, (const uint8_t*)d_msg, (uint32_t*)d_c0, (uint32_t*)d_c1, (int32_t*)d_k0, (int32_t*)d_k1,
-                      (uint8_t*)d_packed_be, (uint32_t)count);
-  HIP_TRY(hipGetLastError());
-  return SPP_OK;
-}
-extern "C" int spp_ctx_sync(spp_ctx* ctx) {
-  if (!ctx) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
-  HIP_TRY(hipSetDevice(ctx->device));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  return SPP_OK;
-}
-
-extern "C" int spp_poseidon_hash_batch(spp_ctx* ctx, size_t count, int arity, const uint8_t* in, uint8_t* out) {
-  if (!ctx || !in || !out) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
-  if (arity != 2 && arity != 4) return fail(SPP_ERR_BAD_INPUT, "arity must be 2 or 4");
-  if (count == 0) return SPP_OK;
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_TRY(hipSetDevice(ctx->device));
-  if (int e = ensure_ctx_consts(ctx)) return e;
-  hipStream_t st = ctx->stream;
-  DevBuf di, dout;
-  UP(di, in, count * arity * 32);
-  HIP_TRY(dout.alloc(count * 32));
-  launch_poseidon_hash(st, ctx->hc, di.as<uint8_t>(), (uint32_t)arity, dout.as<uint8_t>(), (uint32_t)count);
-  HIP_TRY(hipMemcpyAsync(out, dout.p, count * 32, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  HIP_TRY(hipGetLastError());
-  return SPP_OK;
-}
-
-extern "C" int spp_merkle_root_batch(spp_ctx* ctx, size_t count, uint32_t depth, const uint8_t* leaves, const uint64_t* indices,
-                                     const uint8_t* siblings, uint8_t* roots) {
-  if (!ctx || !leaves || !indices || !siblings || !roots) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
-  if (depth == 0 || depth > 64) return fail(SPP_ERR_BAD_INPUT, "depth out of range");
-  if (count == 0) return SPP_OK;
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_TRY(hipSetDevice(ctx->device));
-  if (int e = ensure_ctx_consts(ctx)) return e;
-  hipStream_t st = ctx->stream;
-  DevBuf dl, di, ds, dr;
-  UP(dl, leaves, count * 32); UP(di, indices, count * 8); UP(ds, siblings, count * depth * 32);
-  HIP_TRY(dr.alloc(count * 32));
-  launch_merkle_path(st, ctx->hc, dl.as<uint8_t>(), di.as<uint64_t>(), ds.as<uint8_t>(), depth, dr.as<uint8_t>(), (uint32_t)count);
-  HIP_TRY(hipMemcpyAsync(roots, dr.p, count * 32, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  HIP_TRY(hipGetLastError());
-  return SPP_OK;
-}
-
-// ShieldedPoolMerkleTree.getRoot + getProof (client/merkle.ts:165-221) for a tree of n_leaves inserted leaves
-extern "C" int spp_merkle_build(spp_ctx* ctx, size_t n_leaves, uint32_t depth, const uint8_t* leaves, size_t n_queries,
-                                const uint64_t* query_indices, uint8_t* siblings_out, uint8_t* root_out) {
-  if (!ctx || !root_out || (n_leaves && !leaves) || (n_queries && (!query_indices || !siblings_out)))
-    return fail(SPP_ERR_BAD_INPUT, "NULL argument");
-  if (depth == 0 || depth > 32 || n_leaves > ((size_t)1 << depth)) return fail(SPP_ERR_BAD_INPUT, "bad depth / too many leaves");
-  for (size_t q = 0; q < n_queries; q++)
-    if (query_indices[q] >= ((uint64_t)1 << depth)) return fail(SPP_ERR_BAD_INPUT, "query index out of range");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_TRY(hipSetDevice(ctx->device));
-  if (int e = ensure_ctx_consts(ctx)) return e;
-  hipStream_t st = ctx->stream;
-  // level sizes
-  std::vector<size_t> cnt(depth + 1), off(depth + 2, 0);
-  cnt[0] = n_leaves;
-  for (uint32_t i = 0; i < depth; i++) cnt[i + 1] = (cnt[i] + 1) / 2;
-  for (uint32_t i = 0; i <= depth; i++) off[i + 1] = off[i] + std::max<size_t>(cnt[i], 1);
-  DevBuf dleaves, dnodes, ddef;
-  UP(dleaves, leaves, n_leaves * 32);
-  HIP_TRY(dnodes.alloc(off[depth + 1] * sizeof(Fr)));
-  HIP_TRY(ddef.alloc((depth + 1) * sizeof(Fr)));
-  Fr* nodes = dnodes.as<Fr>();
-  launch_fr_from_be(st, dleaves.as<uint8_t>(), nodes, (uint32_t)n_leaves);
-  std::vector<Fr> dflt(depth + 1);
-  dflt[0] = Fr::zero();
-  for (uint32_t i = 0; i < depth; i++) {
-    // default hash of the next level: H(d_i, d_i) -- one lane, read back (depth <= 32 round trips at tree-build time)
-    launch_merkle_level(st, ctx->hc, nullptr, 0, dflt[i], ddef.as<Fr>() + i + 1, 1);
-    HIP_TRY(hipMemcpyAsync(&dflt[i + 1], ddef.as<Fr>() + i + 1, sizeof(Fr), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    launch_merkle_level(st, ctx->hc, nodes + off[i], (uint32_t)cnt[i], dflt[i], nodes + off[i + 1], (uint32_t)cnt[i + 1]);
-  }
-  std::vector<Fr> host(off[depth + 1]);
-  HIP_TRY(hipMemcpyAsync(host.data(), nodes, host.size() * sizeof(Fr), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  HIP_TRY(hipGetLastError());
-  Fr root = cnt[depth] ? host[off[depth]] : dflt[depth];
-  root.to_bytes_be(root_out);
-  for (size_t q = 0; q < n_queries; q++) {
-    uint64_t idx = query_indices[q];
-    for (uint32_t i = 0; i < depth; i++) {
-      uint64_t sib = idx ^ 1;
-      Fr v = sib < cnt[i] ? host[off[i] + sib] : dflt[i];
-      v.to_bytes_be(siblings_out + (q * depth + i) * 32);
-      idx >>= 1;
-    }
-  }
-  return SPP_OK;
-}
-
-extern "C" int spp_grumpkin_keygen_batch(spp_ctx* ctx, size_t count, const uint8_t* sk, uint8_t* xy) {
-  if (!ctx || !sk || !xy) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
-  if (count == 0) return SPP_OK;
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_TRY(hipSetDevice(ctx->device));
-  if (int e = ensure_ctx_consts(ctx)) return e;
-  hipStream_t st = ctx->stream;
-  DevBuf ds, dx;
-  UP(ds, sk, count * 32);
-  HIP_TRY(dx.alloc(count * 64));
-  launch_grumpkin_keygen(st, ctx->gk_table, ds.as<uint8_t>(), dx.as<uint8_t>(), (uint32_t)count);
-  HIP_TRY(hipMemcpyAsync(xy, dx.p, count * 64, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  HIP_TRY(hipGetLastError());
-  return SPP_OK;
-}
-
-extern "C" int spp_poseidon2_sponge_batch(spp_ctx* ctx, size_t count, uint32_t n, const uint8_t* in, uint8_t* out) {
-  if (!ctx || !in || !out) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
-  if (count == 0) return SPP_OK;
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_TRY(hipSetDevice(ctx->device));
-  if (int e = ensure_ctx_consts(ctx)) return e;
-  hipStream_t st = ctx->stream;
-  DevBuf di, dout;
-  UP(di, in, count * n * 32);
-  HIP_TRY(dout.alloc(count * 32));
-  launch_poseidon2_sponge(st, ctx->hc, di.as<uint8_t>(), n, dout.as<uint8_t>(), (uint32_t)count);
-  HIP_TRY(hipMemcpyAsync(out, dout.p, count * 32, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  HIP_TRY(hipGetLastError());
-  return SPP_OK;
-}
-
-// -----------------------------------------------------------------------------------------------------
-// general-base Pippenger MSM (BASELINE.json configs[4])
-// -----------------------------------------------------------------------------------------------------
-static G1Affine pippenger_finish(const G1XYZZ* d_windows) {
-  // Horner over the 16 window sums: r = sum_j 2^(16 j) W_j
-  std::vector<G1XYZZ> w(pippenger_windows());
-  hipMemcpy(w.data(), d_windows, sizeof(G1XYZZ) * w.size(), hipMemcpyDeviceToHost);
-  G1XYZZ r = G1XYZZ::infinity();
-  for (int j = (int)w.size() - 1; j >= 0; j--) {
-    for (int k = 0; k < 16; k++) r.dbl_inplace();
-    r.add(w[j]);
-  }
-  return r.to_affine();
-}
-
-extern "C" int spp_msm_g1_pippenger(spp_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[64]) {
-  if (!ctx || !out || (n && (!bases || !scalars))) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
-  if (n >= (1u << 31)) return fail(SPP_ERR_BAD_INPUT, "too many points");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t st = ctx->stream;
-  std::vector<G1Affine> pts(n);
-  std::vector<Fr> sc(n);
-  for (size_t i = 0; i < n; i++) {
-    pts[i] = g1_from_raw(bases + 64 * i);
-    sc[i] = Fr::from_bytes_be(scalars + 32 * i);
-  }
-  DevBuf dp, ds, dw;
-  UP(dp, pts.data(), n * sizeof(G1Affine));
-  UP(ds, sc.data(), n * sizeof(Fr));
-  HIP_TRY(dw.alloc(pippenger_workspace_bytes((uint32_t)n)));
-  G1XYZZ* win = nullptr;
-  launch_pippenger_g1(st, dp.as<G1Affine>(), ds.as<Fr>(), (uint32_t)n, dw.p, &win, nullptr, nullptr);
-  HIP_TRY(hipStreamSynchronize(st));
-  HIP_TRY(hipGetLastError());
-  g1_to_raw(pippenger_finish(win), out);
-  return SPP_OK;
-}
-
-// Synthetic micro-benchmark, everything on the device: bases_i = k_i * G (k_i from a 64-bit LCG of `seed`), scalars
-// uniform 254-bit values from the same generator; runs `iters` MSMs, returns the result of the last one, the mean
-// wall time of one MSM and the mean duration of the bucket-accumulation kernel (HIP events).
-// scale: if nonzero, every scalar is multiplied by it first (linearity checks: MSM(scale * s) = scale * MSM(s)).
-extern "C" int spp_msm_g1_pippenger_bench(spp_ctx* ctx, size_t n, uint64_t seed, const uint8_t scale_be[32], int iters, uint8_t out[64],
-                                          float* ms_total, float* ms_bucket_kernel) {
-  return spp_msm_g1_pippenger_bench_dist(ctx, n, seed, 0, scale_be, iters, out, ms_total, ms_bucket_kernel);
-}
-extern "C" int spp_msm_g1_pippenger_bench_dist(spp_ctx* ctx, size_t n, uint64_t seed, uint32_t small_permille, const uint8_t scale_be[32],
-                                               int iters, uint8_t out[64], float* ms_total, float* ms_bucket_kernel) {
-  if (!ctx || !out || n == 0 || iters <= 0 || small_permille > 1000) return fail(SPP_ERR_BAD_INPUT, "bad argument");
-  if (n > (1u << 26)) return fail(SPP_ERR_BAD_INPUT, "n too large");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t st = ctx->stream;
-  // host-generated scalars (n * 32 B; 512 MiB at 2^24) uploaded once
-  std::vector<Fr> ks(n), sc(n);
-  uint64_t x = seed * 6364136223846793005ull + 1442695040888963407ull;
-  auto next = [&]() { x = x * 6364136223846793005ull + 1442695040888963407ull; return x; };
-  Fr scale = Fr::one();
-  if (scale_be) scale = Fr::from_bytes_be(scale_be);
-  for (size_t i = 0; i < n; i++) {
-    ks[i] = Fr::from_u64(next() | 1);
-    uint32_t w[8];
-    for (int k = 0; k < 8; k += 2) { uint64_t v = next(); w[k] = (uint32_t)v; w[k + 1] = (uint32_t)(v >> 32); }
-    w[7] &= 0x1fffffffu;   // < 2^253 < r
-    Fr s;
-    for (int k = 0; k < 8; k++) s.l[k] = w[k];
-    // witness-like: a byte-sized VALUE (Config 5); the uniform ones are raw words of a random element anyway
-    if (small_permille && (next() >> 20) % 1000 < small_permille) s = Fr::from_u64(w[0] & 0xffu);
-    sc[i] = scale_be ? s * scale : s;   // both are fixed representations of the same field element family
-  }
-  DevBuf dk, ds, dp, dw, dt, dg, dtmp, dpre;
-  UP(dk, ks.data(), n * sizeof(Fr));
-  UP(ds, sc.data(), n * sizeof(Fr));
-  HIP_TRY(dp.alloc(n * sizeof(G1Affine)));
-  HIP_TRY(dw.alloc(pippenger_workspace_bytes((uint32_t)n)));
-  // bases = k_i * G through the generator's window table
-  const uint32_t cb = 8, Wn = msm_windows(cb), E = 1u << (cb - 1);
-  G1Affine g1{Fq::from_u64(1), Fq::from_u64(2)};
-  UP(dg, &g1, sizeof g1);
-  const size_t gr = ((size_t)Wn + 63) / 64 * 64;
-  HIP_TRY(dt.alloc(sizeof(G1Affine) * msm_table_elems(1, cb)));
-  HIP_TRY(dtmp.alloc(sizeof(G1XYZZ) * gr * E));
-  HIP_TRY(dpre.alloc(sizeof(Fq) * gr * E));
-  launch_build_table<Fq>(st, dg.as<G1Affine>(), 1, cb, 0, (uint32_t)gr, dt.as<G1Affine>(), dtmp.as<G1XYZZ>(), dpre.as<Fq>());
-  launch_fixed_base_mul<Fq>(st, dt.as<G1Affine>(), cb, dk.as<Fr>(), (uint32_t)n, dp.as<G1Affine>(), nullptr);
-  HIP_TRY(hipStreamSynchronize(st));
-  hipEvent_t e0, e1, k0, k1;
-  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&k0)); HIP_TRY(hipEventCreate(&k1));
-  G1XYZZ* win = nullptr;
-  launch_pippenger_g1(st, dp.as<G1Affine>(), ds.as<Fr>(), (uint32_t)n, dw.p, &win, nullptr, nullptr);   // warm-up
-  HIP_TRY(hipStreamSynchronize(st));
-  float tot = 0, kern = 0;
-  for (int it = 0; it < iters; it++) {
-    hipEventRecord(e0, st);
-    launch_pippenger_g1(st, dp.as<G1Affine>(), ds.as<Fr>(), (uint32_t)n, dw.p, &win, k0, k1);
-    hipEventRecord(e1, st);
-    HIP_TRY(hipStreamSynchronize(st));
-    float a = 0, b = 0;
-    hipEventElapsedTime(&a, e0, e1);
-    hipEventElapsedTime(&b, k0, k1);
-    tot += a;
-    kern += b;
-  }
-  HIP_TRY(hipGetLastError());
-  hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(k0); hipEventDestroy(k1);
-  if (ms_total) *ms_total = tot / iters;
-  if (ms_bucket_kernel) *ms_bucket_kernel = kern / iters;
-  g1_to_raw(pippenger_finish(win), out);
-  return SPP_OK;
-}
-
-// -----------------------------------------------------------------------------------------------------
-// verification (host): `sunspot verify <vk> <proof> <pw>`
-// -----------------------------------------------------------------------------------------------------
-extern "C" int spp_verify(const uint8_t* vk, size_t vk_len, const uint8_t* proof, size_t proof_len, const uint8_t* pw, size_t pw_len,
-                          int* ok) {
-  if (!vk || !proof || !pw || !ok) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
-  *ok = 0;
-  if (proof_len != SPP_PROOF_LEN) return fail(SPP_ERR_FORMAT, "proof must be %d bytes", SPP_PROOF_LEN);
-  auto be32 = [](const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; };
-  if (vk_len < 576 + 4) return fail(SPP_ERR_FORMAT, "verifying key too short");
-  G1Affine alpha1 = g1_from_raw(vk);
-  G2Affine beta2 = g2_from_raw(vk + 128), gamma2 = g2_from_raw(vk + 256), delta2 = g2_from_raw(vk + 448);
-  uint32_t nk = be32(vk + 576);
-  size_t off = 580;
-  if (nk < 2 || vk_len != off + (size_t)nk * 64 + 12 + 256) return fail(SPP_ERR_FORMAT, "verifying key has the wrong length");
-  std::vector<G1Affine> K(nk);
-  for (uint32_t i = 0; i < nk; i++) K[i] = g1_from_raw(vk + off + 64 * (size_t)i);
-  off += (size_t)nk * 64;
-  if (be32(vk + off) != 1 || be32(vk + off + 4) != 0 || be32(vk + off + 8) != 1) return fail(SPP_ERR_FORMAT, "unsupported commitment layout");
-  G2Affine pedG = g2_from_raw(vk + off + 12), pedGS = g2_from_raw(vk + off + 12 + 128);
-  if (pw_len < 12) return fail(SPP_ERR_FORMAT, "public witness too short");
-  uint32_t npub = be32(pw);
-  if (be32(pw + 4) != 0 || be32(pw + 8) != npub || pw_len != 12 + 32 * (size_t)npub || npub + 2 != nk)
-    return fail(SPP_ERR_FORMAT, "public witness does not match the verifying key");
-  if (be32(proof + 256) != 1) return fail(SPP_ERR_FORMAT, "proof must carry exactly one commitment");
-  // canonical encodings only (gnark's readers refuse a coordinate >= q or a witness word >= r; reducing them would make
-  // v and v + r two byte strings for the same nullifier)
-  for (size_t o : {0, 32, 64, 96, 128, 160, 192, 224, 260, 292, 324, 356})
-    if (!be_is_canonical<FqParams>(proof + o)) return SPP_OK;   // ok = 0
-  for (uint32_t i = 0; i < npub; i++)
-    if (!be_is_canonical<FrParams>(pw + 12 + 32 * (size_t)i)) return SPP_OK;
-  G1Affine Ar = g1_from_raw(proof), Krs = g1_from_raw(proof + 192), Cm = g1_from_raw(proof + 260), Pok = g1_from_raw(proof + 324);
-  G2Affine Bs = g2_from_raw(proof + 64);
-  if (!g1_on_curve(Ar) || !g1_on_curve(Krs) || !g1_on_curve(Cm) || !g1_on_curve(Pok) || !g2_on_curve(Bs)) return SPP_OK;   // ok = 0
-  if (!g2_in_subgroup(Bs)) return SPP_OK;   // the twist has a large cofactor: Bs must lie in the order-r subgroup
-  // Pedersen proof of knowledge of the commitment, gnark-crypto's current convention (VerifyingKey{G, GSigmaNeg = -sigma G},
-  // PoK = sum v_i * sigma Basis_i):  e(Cm, GSigmaNeg) * e(PoK, G) == 1
-  if (!pairing_product_is_one({{Cm, pedGS}, {Pok, pedG}})) return SPP_OK;
-  // challenge = hash_to_field(commitment, "bsb22-commitment")
-  const char* dst = "bsb22-commitment";
-  uint8_t u[48];
-  expand_message_xmd(proof + 260, 64, (const uint8_t*)dst, strlen(dst), u, 48);
-  uint32_t w12[12];
-  for (int k = 0; k < 12; k++) w12[k] = be32(u + 4 * k);
-  Fr challenge = fr_from_wide48(w12);
-  G1XYZZ ksum = G1XYZZ::from_affine(K[0]);
-  for (uint32_t i = 0; i <= npub; i++) {
-    Fr v = i < npub ? Fr::from_bytes_be(pw + 12 + 32 * (size_t)i) : challenge;
-    uint32_t lim[8];
-    v.to_canonical(lim);
-    ksum.add(scalar_mul(K[i + 1], lim));
-  }
-  ksum.madd(Cm);
-  if (pairing_product_is_one({{Ar, Bs}, {alpha1.neg(), beta2}, {ksum.to_affine().neg(), gamma2}, {Krs.neg(), delta2}})) *ok = 1;
-  return SPP_OK;
-}
-
-// -----------------------------------------------------------------------------------------------------
-// batched verification on the GPU: same decisions as spp_verify above, one lane per proof
-// -----------------------------------------------------------------------------------------------------
-extern "C" int spp_verify_batch(spp_ctx* ctx, const uint8_t* vk, size_t vk_len, size_t count, const uint8_t* proofs, const uint8_t* pws,
-                                size_t pw_len, int32_t* ok, float* kernel_ms) {
-  if (!ctx || !vk || !ok || (count && (!proofs || !pws))) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
-  if (kernel_ms) *kernel_ms = 0;
-  if (count == 0) return SPP_OK;
-  if (count > (1u << 24)) return fail(SPP_ERR_BAD_INPUT, "count too large");
-  auto be32 = [](const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; };
-  if (vk_len < 576 + 4) return fail(SPP_ERR_FORMAT, "verifying key too short");
-  const uint32_t nk = be32(vk + 576);
-  size_t off = 580;
-  if (nk < 2 || vk_len != off + (size_t)nk * 64 + 12 + 256) return fail(SPP_ERR_FORMAT, "verifying key has the wrong length");
-  if (pw_len != 12 + 32 * (size_t)(nk - 2)) return fail(SPP_ERR_FORMAT, "public witness length does not match the verifying key");
-  const G1Affine alpha1 = g1_from_raw(vk);
-  const G2Affine beta2 = g2_from_raw(vk + 128), gamma2 = g2_from_raw(vk + 256), delta2 = g2_from_raw(vk + 448);
-  std::vector<G1Affine> K(nk);
-  for (uint32_t i = 0; i < nk; i++) K[i] = g1_from_raw(vk + off + 64 * (size_t)i);
-  off += (size_t)nk * 64;
-  if (be32(vk + off) != 1 || be32(vk + off + 4) != 0 || be32(vk + off + 8) != 1) return fail(SPP_ERR_FORMAT, "unsupported commitment layout");
-  const G2Affine pedG = g2_from_raw(vk + off + 12), pedGS = g2_from_raw(vk + off + 12 + 128);
-  for (const G2Affine* q : {&beta2, &gamma2, &delta2, &pedG, &pedGS})
-    if (q->is_inf() || !g2_on_curve(*q)) return fail(SPP_ERR_FORMAT, "verifying key holds an invalid G2 point");
-  if (!pairing_fast_consts_consistent()) return fail(SPP_ERR_HIP, "internal: Frobenius constants are not two-term");
-
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t st = ctx->stream;
-  // per-key preparation on the host: line tables of the four key-side G2 points, e(-alpha, beta), constants
-  VerifyKeyDev h;
-  h.pc = make_pairing_fast_consts();
-  h.e_alpha_beta = f12_from(miller_loop(alpha1.neg(), beta2));
-  h.twist_b = twist_b();
-  h.nk = nk;
-  DevBuf dtab[4], dK, dvk, dproofs, dpws, dok;
-  const G2Affine* qs[4] = {&gamma2, &delta2, &pedG, &pedGS};
-  std::vector<LineStep> tabs_host[4];   // stay alive until the stream has been synchronised
-  for (int k = 0; k < 4; k++) {
-    tabs_host[k] = build_line_table(*qs[k]);
-    UP(dtab[k], tabs_host[k].data(), tabs_host[k].size() * sizeof(LineStep));
-    h.tab[k] = dtab[k].as<LineStep>();
-  }
-  UP(dK, K.data(), K.size() * sizeof(G1Affine));
-  h.K = dK.as<G1Affine>();
-  UP(dvk, &h, sizeof h);
-  UP(dproofs, proofs, count * (size_t)SPP_PROOF_LEN);
-  UP(dpws, pws, count * pw_len);
-  HIP_TRY(dok.alloc(count * sizeof(int32_t)));
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
-  hipEventRecord(e0, st);
-  launch_verify(st, dvk.as<VerifyKeyDev>(), dproofs.as<uint8_t>(), dpws.as<uint8_t>(), (uint32_t)pw_len, (uint32_t)count, dok.as<int32_t>());
-  hipEventRecord(e1, st);
-  HIP_TRY(hipStreamSynchronize(st));
-  HIP_TRY(hipGetLastError());
-  float ms = 0;
-  hipEventElapsedTime(&ms, e0, e1);
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
-  if (kernel_ms) *kernel_ms = ms;
-  HIP_TRY(hipMemcpy(ok, dok.p, count * sizeof(int32_t), hipMemcpyDeviceToHost));
-  return SPP_OK;
-}
-
-// prod_k e(P_k, Q_k) == 1 on the GPU with the device pairing code of the batched verifier (k_pairing_check).
-extern "C" int spp_pairing_check(spp_ctx* ctx, uint32_t n_pairs, const uint8_t* g1s, const uint8_t* g2s, int* ok) {
-  if (!ctx || !g1s || !g2s || !ok) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
-  *ok = 0;
-  if (n_pairs < 1 || n_pairs > 4) return fail(SPP_ERR_BAD_INPUT, "1 to 4 pairs");
-  for (uint32_t k = 0; k < n_pairs; k++) {
-    for (int o = 0; o < 64; o += 32)
-      if (!be_is_canonical<FqParams>(g1s + 64 * k + o)) return fail(SPP_ERR_FORMAT, "G1 coordinate not below q");
-    for (int o = 0; o < 128; o += 32)
-      if (!be_is_canonical<FqParams>(g2s + 128 * k + o)) return fail(SPP_ERR_FORMAT, "G2 coordinate not below q");
-  }
-  if (!pairing_fast_consts_consistent()) return fail(SPP_ERR_HIP, "internal: Frobenius constants are not two-term");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t st = ctx->stream;
-  PairingCheckDev h;
-  h.pc = make_pairing_fast_consts();
-  h.twist_b = twist_b();
-  h.n = n_pairs;
-  DevBuf dtab[3], darg, dok;
-  std::vector<LineStep> tabs_host[3];
-  for (uint32_t k = 0; k < 4; k++) {
-    h.P[k] = k < n_pairs ? g1_from_raw(g1s + 64 * k) : G1Affine::infinity();
-    h.Q[k] = k < n_pairs ? g2_from_raw(g2s + 128 * k) : G2Affine::infinity();
-  }
-  for (uint32_t k = 1; k < 4; k++) {
-    h.tab[k - 1] = nullptr;
-    if (k >= n_pairs) continue;
-    if (h.Q[k].is_inf() || !g2_on_curve(h.Q[k])) return SPP_OK;   // ok = 0 (a line table needs a point of the twist)
-    tabs_host[k - 1] = build_line_table(h.Q[k]);
-    UP(dtab[k - 1], tabs_host[k - 1].data(), tabs_host[k - 1].size() * sizeof(LineStep));
-    h.tab[k - 1] = dtab[k - 1].as<LineStep>();
-  }
-  UP(darg, &h, sizeof h);
-  HIP_TRY(dok.alloc(sizeof(int32_t)));
-  launch_pairing_check(st, darg.as<PairingCheckDev>(), dok.as<int32_t>());
-  HIP_TRY(hipStreamSynchronize(st));
-  HIP_TRY(hipGetLastError());
-  int32_t res = 0;
-  HIP_TRY(hipMemcpy(&res, dok.p, sizeof res, hipMemcpyDeviceToHost));
-  *ok = res;
-  return SPP_OK;
-}
-
-// same product on the host with the single-proof pairing (pairing.hpp): needs no GPU
-extern "C" int spp_pairing_check_host(uint32_t n_pairs, const uint8_t* g1s, const uint8_t* g2s, int* ok) {
-  if (!g1s || !g2s || !ok) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
-  *ok = 0;
-  if (n_pairs < 1 || n_pairs > 8) return fail(SPP_ERR_BAD_INPUT, "1 to 8 pairs");
-  std::vector<std::pair<G1Affine, G2Affine>> pairs;
-  for (uint32_t k = 0; k < n_pairs; k++) {
-    for (int o = 0; o < 64; o += 32)
-      if (!be_is_canonical<FqParams>(g1s + 64 * k + o)) return fail(SPP_ERR_FORMAT, "G1 coordinate not below q");
-    for (int o = 0; o < 128; o += 32)
-      if (!be_is_canonical<FqParams>(g2s + 128 * k + o)) return fail(SPP_ERR_FORMAT, "G2 coordinate not below q");
-    G1Affine P = g1_from_raw(g1s + 64 * k);
-    G2Affine Q = g2_from_raw(g2s + 128 * k);
-    if (!g1_on_curve(P) || Q.is_inf() || !g2_on_curve(Q) || !g2_in_subgroup(Q)) return SPP_OK;
-    pairs.push_back({P, Q});
-  }
-  *ok = pairing_product_is_one(pairs) ? 1 : 0;
-  return SPP_OK;
-}
-
-// -----------------------------------------------------------------------------------------------------
-// audit inputs end to end on the device: (sk, r, e1, e2) -> 3360-field rows for spp_prove_batch(_device)
-// -----------------------------------------------------------------------------------------------------
-static int audit_inputs_on_device(spp_ctx* ctx, const uint32_t* d_pk_a, const uint32_t* d_pk_b, uint32_t count, const uint8_t* d_sk,
-                                  const int8_t* d_r, const int8_t* d_e1, const int8_t* d_e2, uint8_t* d_rows) {
-  hipStream_t st = ctx->stream;
-  DevBuf xy, msg, c0, c1, k0, k1, packed, ct, wa;
-  HIP_TRY(xy.alloc((size_t)count * 64)); HIP_TRY(msg.alloc((size_t)count * 64));
-  HIP_TRY(c0.alloc((size_t)count * 64 * 4)); HIP_TRY(c1.alloc((size_t)count * 1024 * 4));
-  HIP_TRY(k0.alloc((size_t)count * 64 * 4)); HIP_TRY(k1.alloc((size_t)count * 1024 * 4));
-  HIP_TRY(packed.alloc((size_t)count * 157 * 32)); HIP_TRY(ct.alloc((size_t)count * 32)); HIP_TRY(wa.alloc((size_t)count * 32));
-  launch_grumpkin_keygen(st, ctx->gk_table, d_sk, xy.as<uint8_t>(), count);                       // generate_audit.py:482
-  launch_poseidon_hash(st, ctx->hc, xy.as<uint8_t>(), 2, wa.as<uint8_t>(), count);                 // wa_commitment
-  launch_audit_msg(st, xy.as<uint8_t>(), msg.as<uint8_t>(), count);                                // :489-496
-  if (int e = ensure_rlwe(ctx)) return e;
-  launch_rlwe_witness(st, ctx->rlwe, d_pk_a, d_pk_b, d_r, d_e1, d_e2, msg.as<uint8_t>(), c0.as<uint32_t>(), c1.as<uint32_t>(), k0.as<int32_t>(),
-                      k1.as<int32_t>(), packed.as<uint8_t>(), count);                              // :507-584
-  launch_poseidon2_sponge(st, ctx->hc, packed.as<uint8_t>(), 157, ct.as<uint8_t>(), count);        // ct_commitment :587
-  launch_audit_assemble(st, wa.as<uint8_t>(), ct.as<uint8_t>(), packed.as<uint8_t>(), d_sk, d_r, d_e1, d_e2, k0.as<int32_t>(),
-                        k1.as<int32_t>(), d_rows, count);                                          // Prover.toml order :630-641
-  HIP_TRY(hipStreamSynchronize(st));   // temporaries are released on return
-  HIP_TRY(hipGetLastError());
-  return SPP_OK;
-}
-extern "C" int spp_audit_inputs_batch_device(spp_ctx* ctx, const void* d_pk_a, const void* d_pk_b, size_t count, const void* d_sk,
-                                             const void* d_r, const void* d_e1, const void* d_e2, void* d_rows) {
-  if (!ctx || !d_pk_a || !d_pk_b || !d_sk || !d_r || !d_e1 || !d_e2 || !d_rows) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
-  if (count == 0) return SPP_OK;
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_TRY(hipSetDevice(ctx->device));
-  if (int e = ensure_ctx_consts(ctx)) return e;
-  return audit_inputs_on_device(ctx, (const uint32_t*)d_pk_a, (const uint32_t*)d_pk_b, (uint32_t)count, (const uint8_t*)d_sk,
-                                (const int8_t*)d_r, (const int8_t*)d_e1, (const int8_t*)d_e2, (uint8_t*)d_rows);
-}
-extern "C" int spp_audit_inputs_batch(spp_ctx* ctx, const uint32_t* pk_a, const uint32_t* pk_b, size_t count, const uint8_t* sk,
-                                      const int8_t* r, const int8_t* e1, const int8_t* e2, uint8_t* rows) {
-  if (!ctx || !pk_a || !pk_b || !sk || !r || !e1 || !e2 || !rows) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
-  if (count == 0) return SPP_OK;
-  for (int i = 0; i < 1024; i++)
-    if (pk_a[i] >= 167772161u || pk_b[i] >= 167772161u) return fail(SPP_ERR_BAD_INPUT, "public key coefficient not in [0, q)");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_TRY(hipSetDevice(ctx->device));
-  if (int e = ensure_ctx_consts(ctx)) return e;
-  hipStream_t st = ctx->stream;
-  DevBuf da, db, ds, dr, de1, de2, drows;
-  UP(da, pk_a, 4096); UP(db, pk_b, 4096); UP(ds, sk, count * 32);
-  UP(dr, r, count * 1024); UP(de1, e1, count * 64); UP(de2, e2, count * 1024);
-  HIP_TRY(drows.alloc(count * 3360 * 32));
-  if (int e = audit_inputs_on_device(ctx, da.as<uint32_t>(), db.as<uint32_t>(), (uint32_t)count, ds.as<uint8_t>(), dr.as<int8_t>(),
-                                     de1.as<int8_t>(), de2.as<int8_t>(), drows.as<uint8_t>()))
-    return e;
-  HIP_TRY(hipMemcpy(rows, drows.p, count * 3360 * 32, hipMemcpyDeviceToHost));
-  return SPP_OK;
-}
-
-// -----------------------------------------------------------------------------------------------------
-// auditor side: Shamir reconstruction of the RLWE secret key, batch decryption of audit ciphertexts
-// -----------------------------------------------------------------------------------------------------
-extern "C" int spp_shamir_reconstruct(spp_ctx* ctx, uint32_t t, const uint32_t* xs, const uint8_t* ys, size_t n, uint8_t* secret_be,
-                                      uint32_t* sk_mod_q) {
-  if (!ctx || !xs || !ys || (!secret_be && !sk_mod_q)) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
-  if (t == 0 || t > 64) return fail(SPP_ERR_BAD_INPUT, "threshold out of range");
-  for (uint32_t i = 0; i < t; i++)
-    for (uint32_t j = 0; j < i; j++)
-      if (xs[i] == xs[j]) return fail(SPP_ERR_BAD_INPUT, "duplicate share index");
-  if (n == 0) return SPP_OK;
-  // Lagrange coefficients at 0: lambda_i = prod_{j != i} (-x_j) / (x_i - x_j)   (rlwe_decrypt.py:38-51)
-  std::vector<Fr> lam(t);
-  for (uint32_t i = 0; i < t; i++) {
-    Fr num = Fr::one(), den = Fr::one();
-    for (uint32_t j = 0; j < t; j++) {
-      if (i == j) continue;
-      num = num * Fr::from_u64(xs[j]).neg();
-      den = den * (Fr::from_u64(xs[i]) - Fr::from_u64(xs[j]));
-    }
-    lam[i] = num * den.inv();
-  }
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t st = ctx->stream;
-  DevBuf dl, dy, ds, dq;
-  UP(dl, lam.data(), sizeof(Fr) * t);
-  UP(dy, ys, (size_t)t * n * 32);
-  if (secret_be) HIP_TRY(ds.alloc(n * 32));
-  if (sk_mod_q) HIP_TRY(dq.alloc(n * 4));
-  launch_shamir_combine(st, dl.as<Fr>(), dy.as<uint8_t>(), t, (uint32_t)n, secret_be ? ds.as<uint8_t>() : nullptr,
-                        sk_mod_q ? dq.as<uint32_t>() : nullptr);
-  if (secret_be) HIP_TRY(hipMemcpyAsync(secret_be, ds.p, n * 32, hipMemcpyDeviceToHost, st));
-  if (sk_mod_q) HIP_TRY(hipMemcpyAsync(sk_mod_q, dq.p, n * 4, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  HIP_TRY(hipGetLastError());
-  return SPP_OK;
-}
-
-extern "C" int spp_rlwe_decrypt_batch(spp_ctx* ctx, const uint32_t* sk_mod_q, size_t count, const uint32_t* c0, const uint32_t* c1,
-                                      uint8_t* msg) {
-  if (!ctx || !sk_mod_q || !c0 || !c1 || !msg) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
-  if (count == 0) return SPP_OK;
-  for (int i = 0; i < 1024; i++)
-    if (sk_mod_q[i] >= 167772161u) return fail(SPP_ERR_BAD_INPUT, "secret key coefficient not in [0, q)");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t st = ctx->stream;
-  DevBuf dsk, d0, d1, dm;
-  UP(dsk, sk_mod_q, 4096); UP(d0, c0, count * 64 * 4); UP(d1, c1, count * 1024 * 4);
-  HIP_TRY(dm.alloc(count * 64));
-  launch_rlwe_decrypt(st, dsk.as<uint32_t>(), d0.as<uint32_t>(), d1.as<uint32_t>(), dm.as<uint8_t>(), (uint32_t)count);
-  HIP_TRY(hipMemcpyAsync(msg, dm.p, count * 64, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  HIP_TRY(hipGetLastError());
   return SPP_OK;
 }

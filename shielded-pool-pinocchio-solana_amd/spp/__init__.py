@@ -7,4 +7,4 @@ ABI can be inspected), but every proving call needs the compiled library and a H
 from .lib import load_library, SppError, last_error  # noqa: F401
 from .prover import Context, CircuitHandle, build_circuit, verify, pairing_check_host  # noqa: F401
 from .proof_helper import (ShieldedPoolInputs, CircuitConfig, generate_proof, generateProof,  # noqa: F401
-                           generateAuditProof, generate_audit_proof)
+                           generateAuditProof, generate_audit_proof, generateProofBatch, generate_proof_batch)

@@ -72,6 +72,14 @@ def load_library():
     L.spp_poseidon_hash_batch.argtypes = [vp, sz, i32, cp, vp]
     L.spp_merkle_root_batch.argtypes = [vp, sz, u32, cp, vp, cp, vp]
     L.spp_merkle_build.argtypes = [vp, sz, u32, cp, sz, vp, vp, vp]
+    L.spp_merkle_tree_new.argtypes = [vp, u32, ctypes.POINTER(vp)]
+    L.spp_merkle_tree_free.argtypes = [vp]
+    L.spp_merkle_tree_free.restype = None
+    L.spp_merkle_tree_size.argtypes = [vp]
+    L.spp_merkle_tree_size.restype = ctypes.c_uint64
+    L.spp_merkle_tree_insert.argtypes = [vp, sz, cp, ctypes.POINTER(ctypes.c_uint64)]
+    L.spp_merkle_tree_root.argtypes = [vp, vp]
+    L.spp_merkle_tree_proofs.argtypes = [vp, sz, vp, vp]
     L.spp_grumpkin_keygen_batch.argtypes = [vp, sz, cp, vp]
     L.spp_poseidon2_sponge_batch.argtypes = [vp, sz, u32, cp, vp]
     L.spp_audit_inputs_batch.argtypes = [vp, vp, vp, sz, cp, vp, vp, vp, vp]

@@ -77,10 +77,13 @@ def input_vector(inputs: ShieldedPoolInputs):
 _HANDLES = {}
 
 
-def _handle(config: CircuitConfig, window_bits=0):
+def _handle(config: CircuitConfig, window_bits=None):
     """Circuit + proving key resident in HBM, loaded once per (dir, name) -- the reference re-reads
-    .ccs/.pk from disk in every `sunspot prove`."""
+    .ccs/.pk from disk in every `sunspot prove`.  The helper proves one statement (or a handful) per call, so it builds
+    8-bit window tables (~6 GB, under a second) rather than the 225 GB a batch server uses; SPP_WINDOW overrides (0 = auto)."""
     from .prover import Context
+    if window_bits is None:
+        window_bits = int(os.environ.get("SPP_WINDOW", "8"))
     key = (os.path.abspath(config.circuitDir), config.circuitName)
     if key not in _HANDLES:
         target = os.path.join(config.circuitDir, "target")
@@ -114,6 +117,24 @@ def generateProof(config: CircuitConfig, inputs: ShieldedPoolInputs, rs=None):
 
 
 generate_proof = generateProof
+
+
+def generateProofBatch(config: CircuitConfig, inputs_list, rs=None):
+    """Many withdraw proofs in one call (node/proof.helper generateProofBatch; the shape client/payroll-demo.ts:326-352 wants
+    from its Promise.all).  Returns a list of {"proof", "publicWitness"}; raises naming the first unsatisfied index."""
+    if not inputs_list:
+        return []
+    h = _handle(config)
+    if h.circuit_id != SPP_CIRCUIT_WITHDRAW:
+        raise ValueError("generateProofBatch expects the withdraw circuit")
+    proofs, pws, status = h.prove_batch([input_vector(i) for i in inputs_list], rs)
+    for k, st in enumerate(status):
+        if st != 0:
+            raise SppError(st, "inputs of proof %d do not satisfy the circuit" % k)
+    return [{"proof": p, "publicWitness": w} for p, w in zip(proofs, pws)]
+
+
+generate_proof_batch = generateProofBatch
 
 BN254_R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 _AUDIT_ORDER = ("secret_key", "wa_commitment", "ct_commitment", "c0_packed", "c1_packed", "r", "e1_sparse", "e2", "k0", "k1")

@@ -71,29 +71,61 @@ def merkle_roots(ctx, leaves, indices, siblings, depth=TREE_DEPTH):
 
 
 class ShieldedPoolMerkleTree:
-    """client/merkle.ts:146-222 with the level recomputation done on the GPU."""
+    """client/merkle.ts:146-222 with the tree RESIDENT in HBM and maintained incrementally (spp_merkle_tree_*): insert() is
+    O(depth) hashes, getRoot() one read, getProof() `depth` reads -- the reference recomputes up to 2^16 hashes in every
+    getRoot / getProof call (merkle.ts:165-176, 198-221)."""
 
     def __init__(self, ctx, depth=TREE_DEPTH):
-        self.ctx, self.depth, self.leaves = ctx, depth, []
+        self.ctx, self.depth = ctx, depth
+        h = ctypes.c_void_p()
+        check(ctx.L.spp_merkle_tree_new(ctx.h, depth, ctypes.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.ctx.L.spp_merkle_tree_free(self.h)
+            self.h = None
+
+    def __len__(self):
+        return int(self.ctx.L.spp_merkle_tree_size(self.h))
 
     def insert(self, commitment):
-        self.leaves.append(int(commitment))
-        return len(self.leaves) - 1
+        return self.insert_many([commitment])
 
-    def _build(self, queries):
-        nq = len(queries)
-        q = (ctypes.c_uint64 * max(nq, 1))(*[int(i) for i in queries])
-        sib = ctypes.create_string_buffer(32 * self.depth * max(nq, 1))
-        root = ctypes.create_string_buffer(32)
-        check(self.ctx.L.spp_merkle_build(self.ctx.h, len(self.leaves), self.depth, _be(self.leaves), nq, ctypes.cast(q, ctypes.c_void_p),
-                                          ctypes.cast(sib, ctypes.c_void_p), ctypes.cast(root, ctypes.c_void_p)))
-        return int.from_bytes(root.raw, "big"), [_unbe(sib.raw[32 * self.depth * i:], self.depth) for i in range(nq)]
+    def insert_many(self, commitments):
+        """appends the leaves in order; returns the index of the first one"""
+        first = ctypes.c_uint64(0)
+        check(self.ctx.L.spp_merkle_tree_insert(self.h, len(commitments), _be(commitments), ctypes.byref(first)))
+        return int(first.value)
 
     def getRoot(self):
-        return self._build([])[0]
+        root = ctypes.create_string_buffer(32)
+        check(self.ctx.L.spp_merkle_tree_root(self.h, ctypes.cast(root, ctypes.c_void_p)))
+        return int.from_bytes(root.raw, "big")
+
+    def getProofs(self, indices, raw=False):
+        nq = len(indices)
+        q = (ctypes.c_uint64 * max(nq, 1))(*[int(i) for i in indices])
+        sib = ctypes.create_string_buffer(32 * self.depth * max(nq, 1))
+        check(self.ctx.L.spp_merkle_tree_proofs(self.h, nq, ctypes.cast(q, ctypes.c_void_p), ctypes.cast(sib, ctypes.c_void_p)))
+        if raw:
+            return sib.raw[:32 * self.depth * nq]
+        return [_unbe(sib.raw[32 * self.depth * i:], self.depth) for i in range(nq)]
 
     def getProof(self, index):
-        return self._build([index])[1][0]
+        return self.getProofs([index])[0]
+
+
+def merkle_build(ctx, leaves, queries, depth=TREE_DEPTH):
+    """One-shot form (spp_merkle_build): all levels recomputed from the leaves, like the reference's getRoot/getProof.
+    Returns (root, [siblings per query])."""
+    nq = len(queries)
+    q = (ctypes.c_uint64 * max(nq, 1))(*[int(i) for i in queries])
+    sib = ctypes.create_string_buffer(32 * depth * max(nq, 1))
+    root = ctypes.create_string_buffer(32)
+    check(ctx.L.spp_merkle_build(ctx.h, len(leaves), depth, _be(leaves), nq, ctypes.cast(q, ctypes.c_void_p),
+                                 ctypes.cast(sib, ctypes.c_void_p), ctypes.cast(root, ctypes.c_void_p)))
+    return int.from_bytes(root.raw, "big"), [_unbe(sib.raw[32 * depth * i:], depth) for i in range(nq)]
 
 
 def identity_public_keys(ctx, secret_keys):

@@ -30,17 +30,19 @@ def withdraw_rows(ctx, count, seed=2, depth=16, first_index=0):
     idx = list(range(count))
     nulls = W.poseidon_hash_batch(ctx, [[s, i] for s, i in zip(sks, idx)])
     was = W.poseidon_hash_batch(ctx, [[o[0], o[1]] for o in owners])
-    q = (ctypes.c_uint64 * count)(*idx)
-    sib = ctypes.create_string_buffer(32 * depth * count)
-    root = ctypes.create_string_buffer(32)
-    check(ctx.L.spp_merkle_build(ctx.h, count, depth, b"".join(int(c).to_bytes(32, "big") for c in commitments), count,
-                                 ctypes.cast(q, ctypes.c_void_p), ctypes.cast(sib, ctypes.c_void_p), ctypes.cast(root, ctypes.c_void_p)))
+    tree = W.ShieldedPoolMerkleTree(ctx, depth)          # device-resident, incremental (spp_merkle_tree_*)
+    try:
+        assert tree.insert_many(commitments) == 0
+        root_b = tree.getRoot().to_bytes(32, "big")
+        sib_b = tree.getProofs(idx, raw=True)
+    finally:
+        tree.close()
     be = lambda v: int(v).to_bytes(32, "big")
     out = bytearray()
     for i in range(count):
-        out += root.raw + be(nulls[i]) + be(recipients[i]) + be(amounts[i]) + be(was[i])
+        out += root_b + be(nulls[i]) + be(recipients[i]) + be(amounts[i]) + be(was[i])
         out += be(sks[i]) + be(owners[i][0]) + be(owners[i][1]) + be(rnds[i]) + be(idx[i])
-        out += sib.raw[32 * depth * i:32 * depth * (i + 1)]
+        out += sib_b[32 * depth * i:32 * depth * (i + 1)]
     return bytes(out)
 
 

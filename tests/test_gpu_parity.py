@@ -568,6 +568,57 @@ def test_poseidon_merkle_grumpkin_kernels(ctx, withdraw_kat):
     assert witness.merkle_roots(ctx, [p[0] for p in paths], [p[1] for p in paths], [p[2] for p in paths]) == [ot.root()] * 2
 
 
+def test_incremental_merkle_tree_interleaved_inserts_and_queries(ctx):
+    """the device-resident incremental tree (spp_merkle_tree_*) against oracle/hashes.MerkleTree (which restates
+    client/merkle.ts:146-222) on an interleaved sequence of single inserts, batch inserts, root reads and proofs -- including
+    proofs for indices that are not inserted yet, capacity growth past the initial 1024 leaves, the one-shot builder
+    (spp_merkle_build) as a second reference, a depth-20 tree and the refusal of non-canonical leaves."""
+    import spp
+    from spp import witness
+    from oracle import hashes as H
+    from oracle.bn254 import R
+    rng = random.Random(44)
+    ot = H.MerkleTree()
+    gt = witness.ShieldedPoolMerkleTree(ctx)
+    try:
+        assert gt.getRoot() == ot.root() == H.default_hashes()[16] and len(gt) == 0
+        assert gt.getProof(5) == ot.proof(5)                              # empty tree: all defaults
+        steps = [1, 1, 1, 2, 5, 1, 64, 1, 100, 333, 1, 700, 1, 1]          # 1211 leaves in the end: crosses 1024
+        for k, n in enumerate(steps):
+            vals = [rng.randrange(R) for _ in range(n)]
+            first = gt.insert_many(vals) if n > 1 else gt.insert(vals[0])
+            assert first == len(ot.leaves)
+            for v in vals:
+                ot.insert(v)
+            assert len(gt) == len(ot.leaves) and gt.getRoot() == ot.root(), k
+            size = len(ot.leaves)
+            qs = sorted({0, size - 1, size // 2, min(size, (1 << 16) - 1), rng.randrange(size), rng.randrange(1 << 16)})
+            assert gt.getProofs(qs) == [ot.proof(q) for q in qs], k
+        # the one-shot builder agrees with the incremental tree on the same leaves
+        root2, sib2 = witness.merkle_build(ctx, ot.leaves, [0, 1000, 1210])
+        assert root2 == gt.getRoot() and sib2 == gt.getProofs([0, 1000, 1210])
+        # every proof verifies through compute_merkle_root on the GPU
+        qs = [rng.randrange(len(ot.leaves)) for _ in range(70)]
+        assert witness.merkle_roots(ctx, [ot.leaves[q] for q in qs], qs, gt.getProofs(qs)) == [ot.root()] * 70
+        with pytest.raises(spp.SppError):
+            gt.insert(R)                                                  # not a canonical field element
+        with pytest.raises(spp.SppError):
+            gt.getProof(1 << 16)
+        assert len(gt) == len(ot.leaves)
+    finally:
+        gt.close()
+    o20 = H.MerkleTree(20)
+    g20 = witness.ShieldedPoolMerkleTree(ctx, 20)
+    try:
+        vals = [rng.randrange(R) for _ in range(9)]
+        g20.insert_many(vals)
+        for v in vals:
+            o20.insert(v)
+        assert g20.getRoot() == o20.root() and g20.getProof(8) == o20.proof(8) and len(g20.getProof(8)) == 20
+    finally:
+        g20.close()
+
+
 def test_poseidon2_sponge_kernel(ctx, rlwe_pk):
     from spp import witness
     from oracle import hashes as H, rlwe
