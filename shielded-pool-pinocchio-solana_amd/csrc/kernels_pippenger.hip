@@ -2,9 +2,14 @@
 // (2^24 points) and any MSM whose bases are not a resident proving key.  SURVEY 8a a6: "digit extract -> bucket
 // sort -> bucket accumulate -> bucket reduce -> window combine".
 //
-//   1. k_pip_count    lane per point: 16 signed 16-bit digits -> histogram[window][bucket]            (u32 atomics)
-//   2. k_pip_scan     block per window: exclusive prefix sum of the 2^15 bucket counts                 (LDS scan)
-//   3. k_pip_scatter  lane per point: (index | sign) into its bucket's segment                        (u32 atomics)
+//   0. k_pip_digits   lane per point: canonical scalar -> 16 signed 16-bit digits (fold sign applied), stored window-major
+//                     as int16 [16][n] -- the later passes read 2 B per point and window instead of a 32 B scalar
+//   1. k_pip_count    one 1024-lane workgroup per (window, tile of 2^20 points): histogram over the 2^15 buckets in LDS
+//                     (128 KB of the CU's 160 KB; ds_add_u32), written out once per tile -- no global atomics
+//   2. k_pip_totals   lane per (window, bucket): bucket totals + exclusive prefix over the tiles;  k_pip_scan: exclusive
+//                     prefix over the buckets of a window                                                       (LDS scan)
+//   3. k_pip_scatter  same workgroups as 1: LDS cursors start at offs[bucket] + prefix[tile][bucket]; a point's slot comes
+//                     from an LDS atomic, (index | sign) goes to its bucket's segment -- again no global atomics
 //   4. k_pip_segments lane per 256-entry segment of a window's sorted list: gathers its points (64 B each) and folds them
 //                     with mixed additions per bucket; k_pip_fixup joins the buckets that span segments
 //   5. k_pip_chunks   lane per 64-bucket chunk: running sums  S = sum B_b,  T = sum (b_local+1) B_b
@@ -21,31 +26,67 @@ namespace spp {
 static constexpr uint32_t PIP_C = 16, PIP_W = 16, PIP_B = 1u << (PIP_C - 1);   // 2^15 buckets per window
 static constexpr uint32_t PIP_CHUNK = 64, PIP_NCHUNK = PIP_B / PIP_CHUNK;
 
-// signed 16-bit window digits of a canonical scalar folded to |s| <= (r-1)/2; returns the fold sign
-__device__ __forceinline__ bool pip_digits(const Fr& s, int32_t (&dig)[PIP_W]) {
+// Signed 16-bit window digits of a canonical scalar, fold sign applied: point i contributes dig[j] * 2^(16 j) * P_i with
+// dig[j] in [-2^15, 2^15 - 1] (int16).  The scalar is folded to |s| <= (r-1)/2 and recoded from the bottom; a window value of
+// exactly 2^15 may stay (+2^15) or carry (-2^15): it carries when the fold sign is + and stays when it is - , so that the
+// stored digit (fold sign applied) is -2^15 in both cases and always fits.  Bucket = |digit| - 1 in [0, 2^15).
+static constexpr uint32_t PIP_TILE_LOG = 20, PIP_TILE = 1u << PIP_TILE_LOG;   // points per counting / scattering workgroup
+__global__ void __launch_bounds__(256) k_pip_digits(const Fr* __restrict__ scalars, uint32_t n, int16_t* __restrict__ digits) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
   uint32_t cl[8], l[8];
-  s.to_canonical(cl);
+  scalars[i].to_canonical(cl);
   const bool neg = canonical_gt_half<FrParams>(cl);
   if (neg) canonical_negate<FrParams>(cl, l);
   else { SPP_UNROLL for (int k = 0; k < 8; k++) l[k] = cl[k]; }
+  const int32_t keep_max = neg ? (int32_t)PIP_B : (int32_t)PIP_B - 1;         // largest window value that does not carry
   uint32_t carry = 0;
   SPP_UNROLL for (int j = 0; j < (int)PIP_W; j++) {
     const uint32_t word = (j & 1) ? (l[j >> 1] >> 16) : (l[j >> 1] & 0xffffu);
-    uint32_t d = word + carry;
-    if (d > PIP_B) { dig[j] = (int32_t)d - 65536; carry = 1; } else { dig[j] = (int32_t)d; carry = 0; }
+    int32_t d = (int32_t)(word + carry);
+    if (d > keep_max) { d -= 65536; carry = 1; } else carry = 0;              // the top window never carries: |s| < 2^253
+    digits[(size_t)j * n + i] = (int16_t)(neg ? -d : d);
   }
-  return neg;
+}
+__device__ __forceinline__ void pip_decode(int16_t v, uint32_t& bucket, uint32_t& sgn) {
+  const int32_t d = v;
+  sgn = d < 0 ? 0x80000000u : 0u;
+  bucket = (uint32_t)(d < 0 ? -d : d) - 1;
 }
 
-__global__ void __launch_bounds__(256) k_pip_count(const Fr* __restrict__ scalars, uint32_t n, uint32_t* __restrict__ hist) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  int32_t dig[PIP_W];
-  pip_digits(scalars[i], dig);
-  SPP_UNROLL for (int j = 0; j < (int)PIP_W; j++) {
-    const int32_t d = dig[j];
-    if (d != 0) atomicAdd(&hist[j * PIP_B + (uint32_t)((d < 0 ? -d : d) - 1)], 1u);
+__global__ void __launch_bounds__(1024) k_pip_count(const int16_t* __restrict__ digits, uint32_t n, uint32_t ntiles,
+                                                    uint32_t* __restrict__ hist_tile) {
+  __shared__ uint32_t lh[PIP_B];                              // 128 KB
+  const uint32_t j = blockIdx.x / ntiles, tile = blockIdx.x % ntiles, t = threadIdx.x;
+  for (uint32_t b = t; b < PIP_B; b += 1024) lh[b] = 0;
+  __syncthreads();
+  const int16_t* dg = digits + (size_t)j * n;
+  const uint32_t lo = tile << PIP_TILE_LOG, hi = min(n, lo + PIP_TILE);
+  for (uint32_t i = lo + t; i < hi; i += 1024) {
+    const int16_t v = dg[i];
+    if (v != 0) {
+      uint32_t b, sg;
+      pip_decode(v, b, sg);
+      atomicAdd(&lh[b], 1u);
+    }
   }
+  __syncthreads();
+  uint32_t* out = hist_tile + ((size_t)j * ntiles + tile) * PIP_B;
+  for (uint32_t b = t; b < PIP_B; b += 1024) out[b] = lh[b];
+}
+// lane per (window, bucket): hist = total over the tiles; hist_tile[tile] becomes the exclusive prefix over the tiles
+__global__ void __launch_bounds__(256) k_pip_totals(uint32_t ntiles, uint32_t* __restrict__ hist_tile, uint32_t* __restrict__ hist) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= PIP_W * PIP_B) return;
+  const uint32_t j = g / PIP_B, b = g % PIP_B;
+  uint32_t run = 0;
+  for (uint32_t tile = 0; tile < ntiles; tile++) {
+    uint32_t* p = hist_tile + ((size_t)j * ntiles + tile) * PIP_B + b;
+    const uint32_t v = *p;
+    *p = run;
+    run += v;
+  }
+  hist[g] = run;
 }
 
 // exclusive scan of one window's 2^15 counts (1024 lanes x 32 counts each)
@@ -68,19 +109,24 @@ __global__ void __launch_bounds__(1024) k_pip_scan(const uint32_t* __restrict__ 
   SPP_UNROLL for (int k = 0; k < 32; k++) o[k] = base + local[k];
 }
 
-__global__ void __launch_bounds__(256) k_pip_scatter(const Fr* __restrict__ scalars, uint32_t n, const uint32_t* __restrict__ offs,
-                                                     uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  int32_t dig[PIP_W];
-  const bool neg = pip_digits(scalars[i], dig);
-  SPP_UNROLL for (int j = 0; j < (int)PIP_W; j++) {
-    const int32_t d = dig[j];
-    if (d == 0) continue;
-    const uint32_t b = (uint32_t)((d < 0 ? -d : d) - 1);
-    const uint32_t pos = atomicAdd(&cursor[j * PIP_B + b], 1u);
-    const uint32_t sgn = ((d < 0) != neg) ? 0x80000000u : 0u;
-    sorted[(size_t)j * n + offs[j * PIP_B + b] + pos] = i | sgn;
+__global__ void __launch_bounds__(1024) k_pip_scatter(const int16_t* __restrict__ digits, uint32_t n, uint32_t ntiles,
+                                                      const uint32_t* __restrict__ offs, const uint32_t* __restrict__ hist_tile,
+                                                      uint32_t* __restrict__ sorted) {
+  __shared__ uint32_t cur[PIP_B];                             // 128 KB: next free slot of every bucket for THIS tile
+  const uint32_t j = blockIdx.x / ntiles, tile = blockIdx.x % ntiles, t = threadIdx.x;
+  const uint32_t* pre = hist_tile + ((size_t)j * ntiles + tile) * PIP_B;
+  for (uint32_t b = t; b < PIP_B; b += 1024) cur[b] = offs[j * PIP_B + b] + pre[b];
+  __syncthreads();
+  const int16_t* dg = digits + (size_t)j * n;
+  uint32_t* out = sorted + (size_t)j * n;
+  const uint32_t lo = tile << PIP_TILE_LOG, hi = min(n, lo + PIP_TILE);
+  for (uint32_t i = lo + t; i < hi; i += 1024) {
+    const int16_t v = dg[i];
+    if (v != 0) {
+      uint32_t b, sg;
+      pip_decode(v, b, sg);
+      out[atomicAdd(&cur[b], 1u)] = i | sg;
+    }
   }
 }
 
@@ -126,7 +172,17 @@ __global__ void __launch_bounds__(256) k_pip_segments(const G1Affine* __restrict
     else if (continues_after) tail[g] = r;
     else buckets[(size_t)j * PIP_B + b] = r;
   };
+  // software pipeline: the index and the (randomly placed, 64 B) base of entry k + 1 are requested before the ~2.3 K
+  // instructions of the addition of entry k, so the HBM round trip of the gather hides behind arithmetic of the same lane
+  uint32_t e = seg[pos];
+  G1Affine p = bases[e & 0x7fffffffu];
   for (uint32_t k = pos; k < end; k++) {
+    const uint32_t e_cur = e;
+    const G1Affine p_cur = p;
+    if (k + 1 < end) {
+      e = seg[k + 1];
+      p = bases[e & 0x7fffffffu];
+    }
     if (k == bend) {                                       // next non-empty bucket starts here
       flush(false);
       acc = XYZZ29<FqParams>::infinity();
@@ -135,10 +191,8 @@ __global__ void __launch_bounds__(256) k_pip_segments(const G1Affine* __restrict
       while (h[b] == 0) b++;
       bend = o[b] + h[b];
     }
-    const uint32_t e = seg[k];
-    const G1Affine p = bases[e & 0x7fffffffu];
-    if (p.is_inf()) continue;
-    acc.madd(p, (e & 0x80000000u) != 0);
+    if (p_cur.is_inf()) continue;
+    acc.madd(p_cur, (e_cur & 0x80000000u) != 0);
   }
   flush(bend > end);
 }
@@ -199,35 +253,40 @@ __global__ void __launch_bounds__(64) k_pip_windows(const G1XYZZ* __restrict__ S
   if (t == 0) out[j] = sh[0];
 }
 
-// workspace layout (u32 words unless noted): hist[W*B] | offs[W*B] | cursor[W*B] | sorted[W*n] ; then XYZZ:
-// buckets[W*B] | S | T | out[W] | head[W*nseg] | tail[W*nseg]
+// workspace layout (u32 words unless noted): hist[W*B] | offs[W*B] | hist_tile[W*ntiles*B] | sorted[W*n] | digits (int16 [W][n],
+// padded to whole words) ; then XYZZ: buckets[W*B] | S | T | out[W] | head[W*nseg] | tail[W*nseg]
 static uint32_t pip_nseg(uint32_t n) { return (n + PIP_SEG - 1) / PIP_SEG + 1; }
+static uint32_t pip_ntiles(uint32_t n) { return n ? (n + PIP_TILE - 1) / PIP_TILE : 1; }
+static size_t pip_words(uint32_t n) {
+  return (size_t)2 * PIP_W * PIP_B + (size_t)PIP_W * pip_ntiles(n) * PIP_B + (size_t)PIP_W * n + ((size_t)PIP_W * n + 1) / 2;
+}
 size_t pippenger_workspace_bytes(uint32_t n) {
-  size_t words = (size_t)3 * PIP_W * PIP_B + (size_t)PIP_W * n;
   size_t pts = (size_t)PIP_W * PIP_B + 2 * (size_t)PIP_W * PIP_NCHUNK + PIP_W + 2 * (size_t)PIP_W * pip_nseg(n);
-  return ((words * 4 + 255) / 256) * 256 + pts * sizeof(G1XYZZ);
+  return ((pip_words(n) * 4 + 255) / 256) * 256 + pts * sizeof(G1XYZZ);
 }
 uint32_t pippenger_windows() { return PIP_W; }
 
 // window sums land in out_windows[16] (device); ev0/ev1 (optional) bracket the bucket-accumulation kernel
 void launch_pippenger_g1(hipStream_t st, const G1Affine* bases, const Fr* scalars, uint32_t n, void* workspace, G1XYZZ** out_windows,
                          hipEvent_t ev0, hipEvent_t ev1) {
+  const uint32_t ntiles = pip_ntiles(n);
   uint32_t* hist = (uint32_t*)workspace;
   uint32_t* offs = hist + PIP_W * PIP_B;
-  uint32_t* cursor = offs + PIP_W * PIP_B;
-  uint32_t* sorted = cursor + PIP_W * PIP_B;
-  size_t words = (size_t)3 * PIP_W * PIP_B + (size_t)PIP_W * n;
-  G1XYZZ* buckets = (G1XYZZ*)((char*)workspace + ((words * 4 + 255) / 256) * 256);
+  uint32_t* hist_tile = offs + PIP_W * PIP_B;
+  uint32_t* sorted = hist_tile + (size_t)PIP_W * ntiles * PIP_B;
+  int16_t* digits = (int16_t*)(sorted + (size_t)PIP_W * n);
+  G1XYZZ* buckets = (G1XYZZ*)((char*)workspace + ((pip_words(n) * 4 + 255) / 256) * 256);
   G1XYZZ* S = buckets + (size_t)PIP_W * PIP_B;
   G1XYZZ* T = S + (size_t)PIP_W * PIP_NCHUNK;
   G1XYZZ* out = T + (size_t)PIP_W * PIP_NCHUNK;
   const uint32_t nseg = pip_nseg(n);
   G1XYZZ* head = out + PIP_W;
   G1XYZZ* tail = head + (size_t)PIP_W * nseg;
-  (void)hipMemsetAsync(hist, 0, sizeof(uint32_t) * 3 * PIP_W * PIP_B, st);   // hist, offs, cursor
-  if (n) hipLaunchKernelGGL(k_pip_count, dim3((n + 255) / 256), dim3(256), 0, st, scalars, n, hist);
+  if (n) hipLaunchKernelGGL(k_pip_digits, dim3((n + 255) / 256), dim3(256), 0, st, scalars, n, digits);
+  hipLaunchKernelGGL(k_pip_count, dim3(PIP_W * ntiles), dim3(1024), 0, st, digits, n, ntiles, hist_tile);
+  hipLaunchKernelGGL(k_pip_totals, dim3(PIP_W * PIP_B / 256), dim3(256), 0, st, ntiles, hist_tile, hist);
   hipLaunchKernelGGL(k_pip_scan, dim3(PIP_W), dim3(1024), 0, st, hist, offs);
-  if (n) hipLaunchKernelGGL(k_pip_scatter, dim3((n + 255) / 256), dim3(256), 0, st, scalars, n, offs, cursor, sorted);
+  hipLaunchKernelGGL(k_pip_scatter, dim3(PIP_W * ntiles), dim3(1024), 0, st, digits, n, ntiles, offs, hist_tile, sorted);
   if (ev0) hipEventRecord(ev0, st);
   hipLaunchKernelGGL(k_pip_segments, dim3((PIP_W * nseg + 255) / 256), dim3(256), 0, st, bases, n, nseg, offs, hist, sorted, buckets, head,
                      tail);
