@@ -195,15 +195,6 @@ static void sbox_emit(fe* x, fe** out) {
   if (out && *out) { (*out)[0] = x2; (*out)[1] = x3; (*out)[2] = x4; (*out)[3] = x5; *out += 4; }
   *x = x5;
 }
-/* Poseidon2 keeps the three-wire S-box: x^2, x^4, x^5 */
-static void sbox_emit_compact(fe* x, fe** out) {
-  fe x2, x4, x5;
-  fe_sqr(&x2, x, &FR);
-  fe_sqr(&x4, &x2, &FR);
-  fe_mul(&x5, &x4, x, &FR);
-  if (out && *out) { (*out)[0] = x2; (*out)[1] = x4; (*out)[2] = x5; *out += 3; }
-  *x = x5;
-}
 /* in-place permutation; if out != NULL, x^2,x^3,x^4,x^5 of every S-box are written consecutively */
 static void poseidon_permute(fe* s, int t, fe* out) {
   const pparams_t* p = &PP[t];
@@ -240,20 +231,20 @@ static void poseidon2_permute(fe s[4], fe* out) {
   int k = 0;
   p2_external(s);
   for (int r = 0; r < 4; r++) {
-    for (int i = 0; i < 4; i++) { fe_add(&s[i], &s[i], &P2_RC[k + i], &FR); sbox_emit_compact(&s[i], &o); }
+    for (int i = 0; i < 4; i++) { fe_add(&s[i], &s[i], &P2_RC[k + i], &FR); sbox_emit(&s[i], &o); }
     k += 4;
     p2_external(s);
   }
   for (int r = 0; r < 56; r++) {
     fe_add(&s[0], &s[0], &P2_RC[k], &FR);
-    sbox_emit_compact(&s[0], &o);
+    sbox_emit(&s[0], &o);
     k++;
     fe tot = s[0];
     for (int i = 1; i < 4; i++) fe_add(&tot, &tot, &s[i], &FR);
     for (int i = 0; i < 4; i++) { fe m; fe_mul(&m, &P2_MU[i], &s[i], &FR); fe_add(&s[i], &m, &tot, &FR); }
   }
   for (int r = 0; r < 4; r++) {
-    for (int i = 0; i < 4; i++) { fe_add(&s[i], &s[i], &P2_RC[k + i], &FR); sbox_emit_compact(&s[i], &o); }
+    for (int i = 0; i < 4; i++) { fe_add(&s[i], &s[i], &P2_RC[k + i], &FR); sbox_emit(&s[i], &o); }
     k += 4;
     p2_external(s);
   }

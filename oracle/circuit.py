@@ -102,11 +102,12 @@ def _poseidon2_native(state, out, w):
 
     def sbox(x):
         nonlocal out
-        x2 = x * x % R            # Poseidon2 keeps the three-wire S-box (x^2, x^4, x^5)
-        x4 = x2 * x2 % R
+        x2 = x * x % R            # four wires per S-box, as Poseidon: x^2, x^3, x^4, x^5 (B side of every row = x)
+        x3 = x2 * x % R
+        x4 = x3 * x % R
         x5 = x4 * x % R
-        w[out], w[out + 1], w[out + 2] = x2, x4, x5
-        out += 3
+        w[out], w[out + 1], w[out + 2], w[out + 3] = x2, x3, x4, x5
+        out += 4
         return x5
     for _ in range(4):
         s = [sbox((s[i] + rc[k + i]) % R) for i in range(4)]

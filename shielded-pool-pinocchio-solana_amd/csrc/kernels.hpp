@@ -131,9 +131,9 @@ size_t msm_table_elems(uint32_t N, uint32_t c);
 template <class F>
 void launch_msm_accumulate(hipStream_t st, const Affine<F>* table, const uint32_t* rows, const Fr* scalars, XYZZ<F>* partial, uint32_t N,
                            uint32_t P, uint32_t c, uint32_t S, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
-// out[p] = sum_s partial[s][p]   (S = 0: out[p] = infinity)
+// out[p] = sum_s partial[s][p]   (S = 0: out[p] = infinity); folds in place: `partial` is scratch afterwards
 template <class F>
-void launch_msm_reduce(hipStream_t st, const XYZZ<F>* partial, XYZZ<F>* out, uint32_t P, uint32_t S);
+void launch_msm_reduce(hipStream_t st, XYZZ<F>* partial, XYZZ<F>* out, uint32_t P, uint32_t S);
 uint32_t msm_windows(uint32_t c);
 uint32_t msm_slices(uint32_t N, uint32_t P);
 

@@ -12,7 +12,7 @@
 // scalar loads are one coalesced 2 KiB row, table gathers hit one 2^(c-1)*64 B segment, control flow is
 // uniform, and windows in which every proof has a zero digit (bits, bytes, small signed noise -- most of
 // the audit witness) are skipped for the whole wave.  Work is split over S slices of the base range to
-// fill 256 CUs; a second kernel folds the S partial sums per proof through LDS.
+// fill 256 CUs; the S partial sums of every proof are then folded pairwise (k_msm_fold, log2 S launches).
 #include <hip/hip_ext.h>
 #include "kernels.hpp"
 #include "f29.hpp"
@@ -212,25 +212,26 @@ __global__ void __launch_bounds__(256) k_msm_fixed(const Affine<F>* __restrict__
   partial[(size_t)slice * P + p] = acc.result();
 }
 
-// fold S partial sums per proof: one 64-lane block per proof
+// fold the S partial sums of every proof: pairwise, one launch per level, every lane busy -- lane (s, p) with s < S_cur - half
+// adds partial[s + half][p] into partial[s][p] (half = ceil(S_cur / 2)); log2(S) launches of S*P/2, S*P/4, ... lanes.  (The
+// first version used one 64-lane block per proof with an LDS tree: most lanes idle, six dependent additions behind barriers;
+// it cost 1.9 ms per G1 set and 10.7 ms for the G2 set on a 4096-proof batch, 12 % of a step.)
 template <class F>
-__global__ void __launch_bounds__(64) k_msm_reduce(const XYZZ<F>* __restrict__ partial, XYZZ<F>* __restrict__ out, uint32_t P,
-                                                   uint32_t S) {
-  __shared__ XYZZ<F> sh[64];
-  const uint32_t p = blockIdx.x, t = threadIdx.x;
-  XYZZ<F> acc = XYZZ<F>::infinity();
-  for (uint32_t s = t; s < S; s += 64) acc.add(partial[(size_t)s * P + p]);
-  sh[t] = acc;
-  __syncthreads();
-  for (uint32_t w = 32; w > 0; w >>= 1) {
-    if (t < w) {
-      XYZZ<F> a = sh[t];
-      a.add(sh[t + w]);
-      sh[t] = a;
-    }
-    __syncthreads();
-  }
-  if (t == 0) out[p] = sh[0];
+__global__ void __launch_bounds__(64) k_msm_fold(XYZZ<F>* __restrict__ partial, XYZZ<F>* __restrict__ out, uint32_t P, uint32_t half,
+                                                 uint32_t S_cur) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t pairs = S_cur - half;
+  if (g >= half * P) return;
+  const uint32_t s = g / P, p = g % P;
+  XYZZ<F> a = partial[(size_t)s * P + p];
+  if (s < pairs) a.add(partial[(size_t)(s + half) * P + p]);
+  if (half == 1) out[p] = a;                       // last level: the result leaves the scratch array
+  else if (s < pairs) partial[(size_t)s * P + p] = a;
+}
+template <class F>
+__global__ void __launch_bounds__(256) k_msm_fill_inf(XYZZ<F>* __restrict__ out, uint32_t P) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < P) out[g] = XYZZ<F>::infinity();
 }
 
 // ev_start / ev_stop (optional): receive the dispatch's own start and stop timestamps (hipExtLaunchKernelGGL), i.e. the
@@ -249,15 +250,26 @@ void launch_msm_accumulate(hipStream_t st, const Affine<F>* table, const uint32_
                         partial, N, P, c, msm_windows(c), S);
 }
 template <class F>
-void launch_msm_reduce(hipStream_t st, const XYZZ<F>* partial, XYZZ<F>* out, uint32_t P, uint32_t S) {
-  hipLaunchKernelGGL(k_msm_reduce<F>, dim3(P), dim3(64), 0, st, partial, out, P, S);
+void launch_msm_reduce(hipStream_t st, XYZZ<F>* partial, XYZZ<F>* out, uint32_t P, uint32_t S) {
+  if (P == 0) return;
+  if (S == 0) {
+    hipLaunchKernelGGL(k_msm_fill_inf<F>, dim3((P + 255) / 256), dim3(256), 0, st, out, P);
+    return;
+  }
+  uint32_t cur = S;
+  do {
+    const uint32_t half = (cur + 1) / 2;
+    const uint64_t lanes = (uint64_t)half * P;
+    hipLaunchKernelGGL(k_msm_fold<F>, dim3((uint32_t)((lanes + 63) / 64)), dim3(64), 0, st, partial, out, P, half, cur);
+    cur = half;
+  } while (cur > 1);
 }
 template void launch_msm_accumulate<Fq>(hipStream_t, const Affine<Fq>*, const uint32_t*, const Fr*, XYZZ<Fq>*, uint32_t, uint32_t, uint32_t,
                                         uint32_t, hipEvent_t, hipEvent_t);
 template void launch_msm_accumulate<Fq2>(hipStream_t, const Affine<Fq2>*, const uint32_t*, const Fr*, XYZZ<Fq2>*, uint32_t, uint32_t,
                                          uint32_t, uint32_t, hipEvent_t, hipEvent_t);
-template void launch_msm_reduce<Fq>(hipStream_t, const XYZZ<Fq>*, XYZZ<Fq>*, uint32_t, uint32_t);
-template void launch_msm_reduce<Fq2>(hipStream_t, const XYZZ<Fq2>*, XYZZ<Fq2>*, uint32_t, uint32_t);
+template void launch_msm_reduce<Fq>(hipStream_t, XYZZ<Fq>*, XYZZ<Fq>*, uint32_t, uint32_t);
+template void launch_msm_reduce<Fq2>(hipStream_t, XYZZ<Fq2>*, XYZZ<Fq2>*, uint32_t, uint32_t);
 
 // ----------------------------------------------------------------------------------------------------
 // setup: out[i] = scalars[i] * G using the window table of the single base G

@@ -7,7 +7,7 @@
 // Every lane of a wave executes the same instruction stream on its own proof (column p of W[.][P]), so
 // there is no divergence and every witness access is a coalesced 2 KiB row segment.  Poseidon / Poseidon2
 // permutations (main.nr:1-9, ct_helper/src/main.nr:15-34) run natively with the state in registers and
-// emit the power wires of every S-box as they go (x^2..x^5 for Poseidon, x^2, x^4, x^5 for Poseidon2).
+// emit the power wires of every S-box as they go (x^2, x^3, x^4, x^5).
 #include "kernels.hpp"
 #include "circuit.hpp"   // opcodes only
 #include "poseidon29.hpp"
@@ -62,18 +62,7 @@ void launch_load_inputs(hipStream_t st, const uint8_t* d_inputs_be, const uint8_
 // ---------------------------------------------------------------------------------------------------
 // native permutations
 // ---------------------------------------------------------------------------------------------------
-// Poseidon2 (audit circuit): x^2, x^4, x^5
-__device__ __forceinline__ Fr dev_sbox_emit_compact(const Fr& x, Fr* __restrict__ W, uint32_t& out, uint32_t P, uint32_t p) {
-  Fr x2 = x.sqr();
-  Fr x4 = x2.sqr();
-  Fr x5 = x4 * x;
-  W[(size_t)out * P + p] = x2;
-  W[(size_t)(out + 1) * P + p] = x4;
-  W[(size_t)(out + 2) * P + p] = x5;
-  out += 3;
-  return x5;
-}
-// Poseidon (withdraw circuit): x^2, x^3, x^4, x^5 (csrc/circuit.cpp sbox5)
+// Poseidon and Poseidon2 S-boxes: x^2, x^3, x^4, x^5 (csrc/circuit.cpp sbox5)
 __device__ __forceinline__ Fr dev_sbox_emit(const Fr& x, Fr* __restrict__ W, uint32_t& out, uint32_t P, uint32_t p) {
   Fr x2 = x.sqr();
   Fr x3 = x2 * x;
@@ -138,20 +127,20 @@ __device__ __noinline__ void dev_poseidon2(Fr (&s)[4], const Fr* __restrict__ rc
   int k = 0;
 #pragma unroll 1
   for (int r = 0; r < 4; r++) {
-    SPP_UNROLL for (int i = 0; i < 4; i++) s[i] = dev_sbox_emit_compact(s[i] + rc[k + i], W, out, P, p);
+    SPP_UNROLL for (int i = 0; i < 4; i++) s[i] = dev_sbox_emit(s[i] + rc[k + i], W, out, P, p);
     k += 4;
     dev_p2_external(s);
   }
 #pragma unroll 1
   for (int r = 0; r < 56; r++) {
-    s[0] = dev_sbox_emit_compact(s[0] + rc[k], W, out, P, p);
+    s[0] = dev_sbox_emit(s[0] + rc[k], W, out, P, p);
     k++;
     Fr tot = s[0] + s[1] + s[2] + s[3];
     SPP_UNROLL for (int i = 0; i < 4; i++) s[i] = mu[i] * s[i] + tot;
   }
 #pragma unroll 1
   for (int r = 0; r < 4; r++) {
-    SPP_UNROLL for (int i = 0; i < 4; i++) s[i] = dev_sbox_emit_compact(s[i] + rc[k + i], W, out, P, p);
+    SPP_UNROLL for (int i = 0; i < 4; i++) s[i] = dev_sbox_emit(s[i] + rc[k + i], W, out, P, p);
     k += 4;
     dev_p2_external(s);
   }
