@@ -58,6 +58,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline circuit only (profiling runs)")
     ap.add_argument("--no-single", action="store_true", help="skip the single-proof latency leg (keeps profiler per-kernel averages clean)")
+    ap.add_argument("--no-host-leg", action="store_true", help="skip the host-buffer (PCIe-inclusive) leg: its chunks overlap on two workspaces and would "
+                                                                "stretch a profiler's per-kernel averages")
     return ap.parse_args(argv)
 
 
@@ -365,18 +367,20 @@ def main():
         # the same rows through the host-buffer entry point (spp_prove_batch: H2D of the inputs, D2H of proofs / public
         # witnesses, synchronous): the PCIe-inclusive rate, reported beside `value`, never as `value`
         import ctypes
-        HB = 4 * B                       # one call with four batches' worth: libspp cuts it into chunks and pipelines them
-        in_host, rs_host = rows_b * 4, rs_bytes * 4
-        ph = ctypes.create_string_buffer(388 * HB)
-        wh = ctypes.create_string_buffer(h.pw_len * HB)
-        sh = (ctypes.c_int32 * HB)()
-        args_h = (h.h, HB, in_host, rs_host, ctypes.cast(ph, ctypes.c_void_p), ctypes.cast(wh, ctypes.c_void_p), ctypes.cast(sh, ctypes.c_void_p))
-        assert h.L.spp_prove_batch(*args_h) == 0
-        assert ph.raw[388 * (HB - 1):388 * HB] == ph.raw[388 * (B - 1):388 * B]      # same inputs, same blinding, same bytes
-        th = time.perf_counter()
-        assert h.L.spp_prove_batch(*args_h) == 0
-        host_rate = HB / (time.perf_counter() - th)
-        del in_host, rs_host
+        host_rate = None
+        if not args.no_host_leg:
+            HB = 4 * B                       # one call with four batches' worth: libspp cuts it into chunks and pipelines them
+            in_host, rs_host = rows_b * 4, rs_bytes * 4
+            ph = ctypes.create_string_buffer(388 * HB)
+            wh = ctypes.create_string_buffer(h.pw_len * HB)
+            sh = (ctypes.c_int32 * HB)()
+            args_h = (h.h, HB, in_host, rs_host, ctypes.cast(ph, ctypes.c_void_p), ctypes.cast(wh, ctypes.c_void_p), ctypes.cast(sh, ctypes.c_void_p))
+            assert h.L.spp_prove_batch(*args_h) == 0
+            assert ph.raw[388 * (HB - 1):388 * HB] == ph.raw[388 * (B - 1):388 * B]      # same inputs, same blinding, same bytes
+            th = time.perf_counter()
+            assert h.L.spp_prove_batch(*args_h) == 0
+            host_rate = HB / (time.perf_counter() - th)
+            del in_host, rs_host
 
         # SURVEY 8d Config 1/2: ONE proof from the reference's own inputs, end to end on the device-resident entry point
         single = None
@@ -444,7 +448,7 @@ def main():
                        "batch_per_gpu": B, "n_distinct_witnesses": n_distinct, "proofs_per_step_all_gpus": total_proofs,
                        "msm_windows": windows, "msm_sizes": sizes, "table_bytes": h.table_bytes, "parallelism": "independent proofs x%d" % world,
                        "pk_bcast_ms": round(bcast_ms, 3), "pk_bytes": pk_bytes, "setup_s": round(setup_s, 2), "load_s": round(load_s, 2),
-                       "rows_synth_s": round(rows_s, 2), "host_buffer_entry_proofs_per_s": round(host_rate, 1),
+                       "rows_synth_s": round(rows_s, 2), "host_buffer_entry_proofs_per_s": None if host_rate is None else round(host_rate, 1),
                        "last_timed_batch_verified": "all %d proofs accepted by spp_verify_batch (GPU), two of them also by spp_verify (host)" % B,
                        "host_buffer_entry_note": "one spp_prove_batch call with host pointers for 4 batches' worth of proofs: PCIe copies included, chunks pipelined inside libspp"},
             "stage_ms_per_step_pipelined": {k: round(v / acc["n"], 3) for k, v in zip(

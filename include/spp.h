@@ -222,6 +222,8 @@ int spp_rlwe_decrypt_batch(spp_ctx* ctx, const uint32_t* sk_mod_q, size_t count,
 int spp_ntt_fr(spp_ctx* ctx, uint8_t* data, uint32_t logn, int inverse);
 /* sum_i scalars[i] * bases[i]; bases 64 B, scalars 32 B (big-endian); out 64 B. Table-based path. */
 int spp_msm_g1(spp_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, int window_bits, uint8_t out[64]);
+/* the same over G2: bases 128 B (gnark raw X.A1 | X.A0 | Y.A1 | Y.A0), out 128 B -- the table walk that produces a proof's Bs */
+int spp_msm_g2(spp_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, int window_bits, uint8_t out[128]);
 
 /* General-base Pippenger (16-bit signed windows, bucket sort + accumulate + reduce) for large n; same conventions. */
 int spp_msm_g1_pippenger(spp_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[64]);

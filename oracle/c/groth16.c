@@ -594,6 +594,25 @@ void orc_msm_g1(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t 
   free(s);
 }
 
+void orc_msm_g2(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[128]) {
+  orc_fields_init();
+  g2a* b = (g2a*)malloc(sizeof(g2a) * (n ? n : 1));
+  uint64_t* s = (uint64_t*)malloc(32 * (n ? n : 1));
+  for (size_t i = 0; i < n; i++) {
+    g2a_from_bytes(&b[i], bases + 128 * i);
+    fe t;
+    fe_from_be(&t, scalars + 32 * i, &FR);
+    fe_to_raw(s + 4 * i, &t, &FR);
+  }
+  g2j r;
+  msm_g2(&r, b, s, n);
+  g2a ra;
+  g2j_to_affine(&ra, &r);
+  g2a_to_bytes(out, &ra);
+  free(b);
+  free(s);
+}
+
 /* ------------------------------------------------------------------------------------------------ */
 /* fixed-base tables for setup                                                                        */
 /* ------------------------------------------------------------------------------------------------ */

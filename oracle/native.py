@@ -28,6 +28,7 @@ def lib():
         L.orc_prove_many.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p]
         L.orc_check_many.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_void_p]
         L.orc_msm_g1.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.orc_msm_g2.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p]
         L.orc_ntt.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int]
         _LIB = L
     return _LIB

@@ -1136,7 +1136,13 @@ extern "C" int spp_setup(spp_ctx* ctx, const char* circuit_path, const uint8_t s
 // -----------------------------------------------------------------------------------------------------
 // table-based MSM over caller-supplied bases (unit entry point; uses the table builder above)
 // -----------------------------------------------------------------------------------------------------
-extern "C" int spp_msm_g1(spp_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, int window_bits, uint8_t out[64]) {
+template <class F> static Affine<F> point_from_raw(const uint8_t* b);
+template <> Affine<Fq> point_from_raw<Fq>(const uint8_t* b) { return g1_from_raw(b); }
+template <> Affine<Fq2> point_from_raw<Fq2>(const uint8_t* b) { return g2_from_raw(b); }
+static void point_to_raw(const G1Affine& p, uint8_t* b) { g1_to_raw(p, b); }
+static void point_to_raw(const G2Affine& p, uint8_t* b) { g2_to_raw(p, b); }
+template <class F, size_t PT_BYTES>
+static int msm_fixed_unit(spp_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, int window_bits, uint8_t* out) {
   if (!ctx || !out || (n && (!bases || !scalars))) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
   if (window_bits == 0) window_bits = 8;
   if (window_bits < 4 || window_bits > 16) return fail(SPP_ERR_BAD_INPUT, "window_bits outside [4,16]");
@@ -1145,32 +1151,32 @@ extern "C" int spp_msm_g1(spp_ctx* ctx, const uint8_t* bases, const uint8_t* sca
   hipStream_t st = ctx->stream;
   const uint32_t cb = (uint32_t)window_bits, Wn = msm_windows(cb), E = 1u << (cb - 1);
   (void)E;
-  if ((uint64_t)msm_table_elems((uint32_t)n, cb) * 64 > ((uint64_t)64 << 30)) return fail(SPP_ERR_BAD_INPUT, "table would exceed 64 GiB; use a smaller window");
-  std::vector<G1Affine> pts(n);
+  if ((uint64_t)msm_table_elems((uint32_t)n, cb) * PT_BYTES > ((uint64_t)64 << 30)) return fail(SPP_ERR_BAD_INPUT, "table would exceed 64 GiB; use a smaller window");
+  std::vector<Affine<F>> pts(n);
   std::vector<Fr> sc(n);
   std::vector<uint32_t> rows(n);
   for (size_t i = 0; i < n; i++) {
-    pts[i] = g1_from_raw(bases + 64 * i);
+    pts[i] = point_from_raw<F>(bases + PT_BYTES * i);
     sc[i] = Fr::from_bytes_be(scalars + 32 * i);
     rows[i] = (uint32_t)i;
   }
   spp_circuit tmpc;   // only used as an owner of device allocations
   tmpc.ctx = ctx;
   tmpc.c_bits = cb;
-  G1Affine* table = nullptr;
-  int e = build_table_chunked<Fq>(&tmpc, pts, cb, &table);
+  Affine<F>* table = nullptr;
+  int e = build_table_chunked<F>(&tmpc, pts, cb, &table);
   Fr* d_sc = nullptr;
   uint32_t* d_rows = nullptr;
-  G1XYZZ *partial = nullptr, *d_out = nullptr;
+  XYZZ<F> *partial = nullptr, *d_out = nullptr;
   uint32_t S = msm_slices((uint32_t)n, 1);
   if (!e) e = own_upload(&tmpc, &d_sc, sc);
   if (!e) e = own_upload(&tmpc, &d_rows, rows);
-  if (!e && hipMalloc((void**)&partial, sizeof(G1XYZZ) * S) != hipSuccess) e = fail(SPP_ERR_HIP, "hipMalloc");
-  if (!e && hipMalloc((void**)&d_out, sizeof(G1XYZZ)) != hipSuccess) e = fail(SPP_ERR_HIP, "hipMalloc");
-  G1XYZZ res = G1XYZZ::infinity();
+  if (!e && hipMalloc((void**)&partial, sizeof(XYZZ<F>) * S) != hipSuccess) e = fail(SPP_ERR_HIP, "hipMalloc");
+  if (!e && hipMalloc((void**)&d_out, sizeof(XYZZ<F>)) != hipSuccess) e = fail(SPP_ERR_HIP, "hipMalloc");
+  XYZZ<F> res = XYZZ<F>::infinity();
   if (!e) {
-    launch_msm_accumulate<Fq>(st, table, d_rows, d_sc, partial, (uint32_t)n, 1, cb, S);
-    launch_msm_reduce<Fq>(st, partial, d_out, 1, n ? S : 0);
+    launch_msm_accumulate<F>(st, table, d_rows, d_sc, partial, (uint32_t)n, 1, cb, S);
+    launch_msm_reduce<F>(st, partial, d_out, 1, n ? S : 0);
     if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) e = fail(SPP_ERR_HIP, "msm kernels failed");
     else if (hipMemcpy(&res, d_out, sizeof res, hipMemcpyDeviceToHost) != hipSuccess) e = fail(SPP_ERR_HIP, "copy back failed");
   }
@@ -1178,6 +1184,13 @@ extern "C" int spp_msm_g1(spp_ctx* ctx, const uint8_t* bases, const uint8_t* sca
   if (partial) hipFree(partial);
   if (d_out) hipFree(d_out);
   if (e) return e;
-  g1_to_raw(res.to_affine(), out);
+  point_to_raw(res.to_affine(), out);
   return SPP_OK;
+}
+extern "C" int spp_msm_g1(spp_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, int window_bits, uint8_t out[64]) {
+  return msm_fixed_unit<Fq, 64>(ctx, bases, scalars, n, window_bits, out);
+}
+// the same walk over G2 bases (128 B, gnark raw X.A1|X.A0|Y.A1|Y.A0): what Bs of a proof comes from (k_msm_fixed<Fq2>)
+extern "C" int spp_msm_g2(spp_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, int window_bits, uint8_t out[128]) {
+  return msm_fixed_unit<Fq2, 128>(ctx, bases, scalars, n, window_bits, out);
 }

@@ -2,7 +2,8 @@
 output-file naming (outputs land next to the circuit file, as sunspot writes them next to the .ccs).
 
     python -m spp.cli compile withdraw|audit [--rlwe-pk rlwe_pk.json] -o target/<name>.sppc     # prints nbConstraints=<n>
-    python -m spp.cli setup   target/<name>.sppc [--seed HEX32]                                   # -> <name>.pk, <name>.vk
+    python -m spp.cli setup   target/<name>.sppc [--seed HEX32] [--force]                         # -> <name>.pk, <name>.vk (+ .setup.json;
+                                                                                                  #    skipped when the keys match the circuit)
     python -m spp.cli prove   target/<name>.sppc target/<name>.pk Prover.toml                    # -> <name>.proof, <name>.pw
     python -m spp.cli verify  target/<name>.vk target/<name>.proof target/<name>.pw              # exit 0 / 1
     python -m spp.cli execute target/<name>.json Prover.toml [-o target/<name>.gz]               # `nargo execute`: ACIR witness stack
@@ -60,6 +61,7 @@ def main(argv=None):
     sub = ap.add_subparsers(dest="cmd", required=True)
     c = sub.add_parser("compile"); c.add_argument("circuit", choices=["withdraw", "audit"]); c.add_argument("--rlwe-pk"); c.add_argument("-o", "--out", required=True)
     s = sub.add_parser("setup"); s.add_argument("sppc"); s.add_argument("--seed", default=None); s.add_argument("--device", type=int, default=0)
+    s.add_argument("--force", action="store_true", help="redo the setup even when matching keys exist")
     p = sub.add_parser("prove"); p.add_argument("files", nargs="+", help="<sppc> <pk> <Prover.toml>  |  <acir.json> <witness.gz> <sppc> <pk>")
     p.add_argument("--device", type=int, default=0)
     p.add_argument("--window", type=int, default=0)
@@ -77,11 +79,28 @@ def main(argv=None):
         print("nbConstraints=%d" % n)
         return 0
     if a.cmd == "setup":
+        # the skip-if-exists step of noir_circuit/prove_linux.sh:72-79 ("if [ ! -f pk ] || [ ! -f vk ]; then sunspot setup"),
+        # made safe: the keys are reused only when <name>.setup.json records the hash of THIS circuit file (and the same
+        # seed, when one is given); a circuit rebuilt with other constraints gets a fresh setup.
+        import hashlib
         base = os.path.splitext(a.sppc)[0]
+        meta_path = base + ".setup.json"
+        digest = hashlib.sha256(open(a.sppc, "rb").read()).hexdigest()
+        if not a.force and all(os.path.exists(base + e) for e in (".pk", ".vk")) and os.path.exists(meta_path):
+            try:
+                meta = json.load(open(meta_path))
+            except Exception:
+                meta = {}
+            if meta.get("circuit_sha256") == digest and (a.seed is None or meta.get("seed_sha256") == hashlib.sha256(bytes.fromhex(a.seed)).hexdigest()) \
+                    and meta.get("pk_bytes") == os.path.getsize(base + ".pk"):
+                print("setup: %s.pk / .vk are up to date for this circuit (use --force to redo)" % base)
+                return 0
         seed = bytes.fromhex(a.seed) if a.seed else os.urandom(32)
         ctx = Context(a.device)
         ctx.setup(a.sppc, seed, base + ".pk", base + ".vk")
         ctx.close()
+        json.dump({"circuit_sha256": digest, "seed_sha256": hashlib.sha256(seed).hexdigest(), "pk_bytes": os.path.getsize(base + ".pk")},
+                  open(meta_path, "w"))
         return 0
     if a.cmd == "execute":
         from . import acir

@@ -65,6 +65,12 @@ class Context:
         check(self.L.spp_msm_g1(self.h, bases_bytes, sc, n, int(window_bits), ctypes.cast(out, ctypes.c_void_p)))
         return out.raw
 
+    def msm_g2(self, bases_bytes, scalars, window_bits=8):
+        out = ctypes.create_string_buffer(128)
+        sc = b"".join(int(s).to_bytes(32, "big") for s in scalars)
+        check(self.L.spp_msm_g2(self.h, bases_bytes, sc, len(scalars), int(window_bits), ctypes.cast(out, ctypes.c_void_p)))
+        return out.raw
+
     def msm_g1_pippenger(self, bases_bytes, scalars):
         out = ctypes.create_string_buffer(64)
         sc = b"".join(int(s).to_bytes(32, "big") for s in scalars)

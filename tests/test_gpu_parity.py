@@ -20,7 +20,7 @@ def test_ntt_matches_oracle(ctx):
     import ctypes
     rng = random.Random(5)
     from oracle.bn254 import R
-    for logn in (1, 4, 8, 9, 13):
+    for logn in (1, 4, 8, 9, 13, 14, 15):      # 2^13 / 2^14 / 2^15 = the proving domains (withdraw, reference-size withdraw, audit)
         n = 1 << logn
         vals = [rng.randrange(R) for _ in range(n)]
         for inverse in (False, True):
@@ -57,6 +57,42 @@ def test_msm_g1_matches_oracle(ctx):
         out = ctypes.create_string_buffer(64)
         native.lib().orc_msm_g1(bases[:64 * n], b"".join(s.to_bytes(32, "big") for s in sc), n, ctypes.cast(out, ctypes.c_void_p))
         assert got == out.raw, (n, wb)
+
+
+def test_msm_g2_matches_oracle(ctx):
+    """The G2 table walk (k_msm_fixed<Fq2>, the MSM behind a proof's Bs) on its own: random twist points and the same scalar
+    edge cases as the G1 test, against the oracle's C Pippenger over Fq2 and, for one case, the Python big-int sum."""
+    from oracle import bn254 as B, native
+    import ctypes
+    rng = random.Random(19)
+    pts = []
+    p = B.G2_GEN
+    for i in range(70):
+        p = B.g2_add(p, B.g2_mul(B.G2_GEN, rng.randrange(1, 1 << 64)))
+        pts.append(p)
+    bases = b"".join(B.g2_to_bytes(q) for q in pts)
+    for n, wb in ((0, 6), (1, 6), (7, 4), (70, 6), (70, 8)):
+        sc = [rng.randrange(B.R) for _ in range(n)]
+        if n >= 7:
+            sc[0], sc[1], sc[2], sc[3], sc[4], sc[5] = 0, 1, B.R - 1, (B.R - 1) // 2, (B.R + 1) // 2, 255
+        got = ctx.msm_g2(bases[:128 * n], sc, wb)
+        out = ctypes.create_string_buffer(128)
+        native.lib().orc_msm_g2(bases[:128 * n], b"".join(s.to_bytes(32, "big") for s in sc), n, ctypes.cast(out, ctypes.c_void_p))
+        assert got == out.raw, (n, wb)
+        if n == 7:
+            acc = None
+            for q, k in zip(pts, sc):
+                acc = B.g2_add(acc, B.g2_mul(q, k))
+            assert got == B.g2_to_bytes(acc)
+    # repeated and cancelling bases: doubling and cancellation paths of XYZZ29G2::madd
+    g = B.g2_mul(B.G2_GEN, 0x77)
+    neg = B.g2_neg(g)
+    mix = [g if i % 3 else neg for i in range(200)]
+    sc = [5] * 200
+    got = ctx.msm_g2(b"".join(B.g2_to_bytes(q) for q in mix), sc, 8)
+    out = ctypes.create_string_buffer(128)
+    native.lib().orc_msm_g2(b"".join(B.g2_to_bytes(q) for q in mix), b"".join(s.to_bytes(32, "big") for s in sc), 200, ctypes.cast(out, ctypes.c_void_p))
+    assert got == out.raw
 
 
 def test_msm_g1_repeated_and_cancelling_bases(ctx):
@@ -751,6 +787,24 @@ def test_cli_setup_prove_verify_on_gpu(tmp_path, withdraw_kat):
     bad = tmp_path / "Bad.toml"
     bad.write_text(toml.read_text().replace('recipient = "0x0000', 'recipient = "0x0001', 1).replace(withdraw_kat["root"], withdraw_kat["nullifier"], 1))
     assert cli.main(["prove", sppc, base + ".pk", str(bad), "--window", "6"]) == 1
+    # skip-if-exists (prove_linux.sh:72-79), keyed by the circuit's hash: same circuit + seed -> keys untouched; another
+    # seed or --force -> redone; a different circuit file under the same name -> redone
+    import json
+    pk_before = open(base + ".pk", "rb").read()
+    mtime = os.path.getmtime(base + ".pk")
+    assert cli.main(["setup", sppc, "--seed", "11" * 32]) == 0 and os.path.getmtime(base + ".pk") == mtime
+    assert cli.main(["setup", sppc]) == 0 and os.path.getmtime(base + ".pk") == mtime          # no seed given: existing keys are fine
+    assert json.load(open(base + ".setup.json"))["pk_bytes"] == len(pk_before)
+    assert cli.main(["setup", sppc, "--seed", "12" * 32]) == 0 and open(base + ".pk", "rb").read() != pk_before
+    assert cli.main(["setup", sppc, "--seed", "11" * 32]) == 0 and open(base + ".pk", "rb").read() == pk_before   # deterministic
+    assert cli.main(["compile", "withdraw", "-o", sppc]) == 0
+    open(sppc, "ab").close()
+    meta = json.load(open(base + ".setup.json")); meta["circuit_sha256"] = "0" * 64
+    json.dump(meta, open(base + ".setup.json", "w"))
+    t0 = os.path.getmtime(base + ".pk")
+    import time
+    time.sleep(0.05)
+    assert cli.main(["setup", sppc, "--seed", "11" * 32]) == 0 and os.path.getmtime(base + ".pk") > t0          # hash mismatch -> redone
 
 
 def test_audit_inputs_pipeline_on_gpu(ctx, rlwe_pk):
