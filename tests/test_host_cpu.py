@@ -399,25 +399,33 @@ def test_no_return_address_clobber_in_device_code(tmp_path):
 
 
 def test_committed_bench_line_follows_the_contract():
-    """The bench line committed under profiles/ (the output of `python bench.py` on the MI355X box) carries every field
-    of the driver's contract, the roofline object and the CPU baseline, with consistent arithmetic."""
-    import glob
+    """The bench line committed under profiles/ (the output of `python bench.py` on the MI355X box, this round) carries every
+    field of the driver's contract, the roofline object and the CPU baseline, with consistent arithmetic; the headline is the
+    audit circuit on a batch of distinct witnesses, and every extra leg ran at least 10 timed steps."""
     import json
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "round1_*_bench_default_run.json")))
-    assert paths
-    j = json.load(open(paths[-1]))
+    j = json.load(open(os.path.join(ROOT, "profiles", "round2_bench_default_run.json")))
     for k, t in (("metric", str), ("value", (int, float)), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                  ("ms_per_step", (int, float)), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict)):
         assert isinstance(j[k], t), k
     assert j["vs_baseline"] is None and j["scaling"] == "weak" and j["higher_is_better"] is True and "workload" in j["config"]
-    assert abs(j["value"] - j["config"]["batch_per_gpu"] * j["n_gpus"] / (j["ms_per_step"] * 1e-3)) / j["value"] < 0.01
+    c = j["config"]
+    assert c["circuit"] == "audit" and c["n_distinct_witnesses"] == c["batch_per_gpu"] == 2048 and j["steps"] >= 10
+    assert abs(j["value"] - c["batch_per_gpu"] * j["n_gpus"] / (j["ms_per_step"] * 1e-3)) / j["value"] < 0.01
     r = j["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5
     assert abs(r["achieved"] - r["alg_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 0.01
+    assert r["launches_per_step"] * r["avg_launch_ms"] <= j["ms_per_step"]          # the dominant kernel's launches fit inside a step
     assert r["traffic"] is None or r["traffic"] > r["alg_bytes_per_launch"]
-    c = j["cpu_baseline"]
-    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == j["unit"] and c["sample"]
+    cb = j["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == j["unit"] and cb["sample"]
+    for leg in ("withdraw_circuit", "withdraw_at_reference_r1cs_size", "withdraw_depth20_variant"):
+        assert j[leg]["steps"] >= 10 and j[leg]["config"]["n_distinct_witnesses"] == j[leg]["config"]["batch_per_gpu"], leg
+    assert j["withdraw_at_reference_r1cs_size"]["config"]["n_constraints"] == 12452
+    assert j["rlwe_witness_2p16"]["iters"] >= 10 and j["msm_g1_2p24"]["iters"] >= 10
+    # the PMC summary the line's `traffic` comes from describes the same workload
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_latest.json")))
+    assert pmc["circuit"] == "audit" and pmc["batch"] == 2048 and pmc["n_distinct_witnesses"] == 2048
 
 
 def _depth20_rows(count):
