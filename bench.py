@@ -41,8 +41,9 @@ INFO_ORDER = ["A", "B1", "K", "Z", "CB", "CS", "B2(G2)"]    # order of spp_circu
 WORKLOADS = {"withdraw": "noir_circuit withdraw (Poseidon Merkle depth 16 + Grumpkin)",
              "withdraw_refshape": "noir_circuit withdraw padded with ballast multiplications to the reference's gnark R1CS size (12 452 constraints, 2^14)",
              "withdraw_depth20": "withdraw statement over a depth-20 Poseidon tree (synthetic variant; the reference is depth 16)",
+             "withdraw_acir": "noir_circuit withdraw, R1CS compiled from the reference's own ACIR (noir_circuit/target/shielded_pool_verifier.json via spp compile)",
              "audit": "audit_circuit (RLWE, const-PK; scripts/generate_audit.py:246-465)"}
-DEFAULT_BATCH = {"withdraw": 4096, "audit": 2048, "withdraw_refshape": 2048, "withdraw_depth20": 2048}
+DEFAULT_BATCH = {"withdraw": 4096, "audit": 2048, "withdraw_refshape": 2048, "withdraw_depth20": 2048, "withdraw_acir": 4096}
 
 
 def parse_args(argv=None):
@@ -253,8 +254,12 @@ def main():
         strong_total > 0: this rank proves rows shard_range(strong_total, rank, world) of the fixed batch."""
         tmp = tempfile.mkdtemp(prefix="spp_bench_%d_" % rank)
         sppc, pkp, vkp = (os.path.join(tmp, "c." + e) for e in ("sppc", "pk", "vk"))
-        cid = {"withdraw": 1, "audit": 2, "withdraw_refshape": 3, "withdraw_depth20": 4}[circuit]
-        spp.build_circuit(cid, sppc, aux=(list(rlwe_pk["a"]) + list(rlwe_pk["b"])) if cid == 2 else None)
+        if circuit == "withdraw_acir":
+            from spp import acir
+            acir.compile_to_sppc(os.path.join(ROOT, "tests", "golden", "reference_withdraw_acir.json"), sppc)
+        else:
+            cid = {"withdraw": 1, "audit": 2, "withdraw_refshape": 3, "withdraw_depth20": 4}[circuit]
+            spp.build_circuit(cid, sppc, aux=(list(rlwe_pk["a"]) + list(rlwe_pk["b"])) if cid == 2 else None)
         ctx = spp.Context(local_rank)
         # ---- proving key: GPU setup on rank 0, one RCCL broadcast over xGMI ----
         t0 = time.time()
@@ -384,8 +389,8 @@ def main():
 
         # SURVEY 8d Config 1/2: ONE proof from the reference's own inputs, end to end on the device-resident entry point
         single = None
-        if circuit in ("withdraw", "audit") and not args.no_single and world == 1:
-            if circuit == "withdraw":
+        if circuit in ("withdraw", "audit", "withdraw_acir") and not args.no_single and world == 1:
+            if circuit != "audit":
                 from oracle import circuit as OC
                 kat_row = OC.withdraw_inputs(json.load(open(os.path.join(ROOT, "tests", "golden", "withdraw_kat.json"))))
                 kat_name = "client/prover-params.toml (tests/golden/withdraw_kat.json)"
@@ -506,6 +511,7 @@ def main():
         extras[other + "_circuit"] = run_circuit(other, DEFAULT_BATCH[other], 10, 3, want)
         extras["withdraw_at_reference_r1cs_size"] = run_circuit("withdraw_refshape", DEFAULT_BATCH["withdraw_refshape"], 10, 3, False)
         extras["withdraw_depth20_variant"] = run_circuit("withdraw_depth20", DEFAULT_BATCH["withdraw_depth20"], 10, 3, False)
+        extras["withdraw_compiled_from_reference_acir"] = run_circuit("withdraw_acir", DEFAULT_BATCH["withdraw_acir"], 10, 3, False)
         ctx = spp.Context(local_rank)
         extras["rlwe_witness_2p16"] = rlwe_leg(ctx, dev, rlwe_pk)
         extras["msm_g1_2p24"] = pippenger_leg(ctx)

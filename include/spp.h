@@ -80,6 +80,15 @@ const char* spp_version(void);
  * Prints nothing; *n_constraints (optional) receives the constraint count (`nbConstraints=` of sunspot compile). */
 int spp_circuit_build(int circuit_id, const uint32_t* aux, const char* out_path, uint32_t* n_constraints);
 
+/* `sunspot compile <acir>` (noir_circuit/prove_linux.sh:66-70) for a program compiled by nargo: lowers the ACIR opcodes --
+ * AssertZero, RANGE, the fixed-base Grumpkin MultiScalarMul and the Brillig hints of the reference's withdraw circuit
+ * (noir_circuit/target/shielded_pool_verifier.json) -- to an R1CS + solver program in the same SPPC container, so the
+ * reference's OWN compiled circuit is what gets set up and proved.  blob: the decoded opcode list written by
+ * spp/acir.py:to_blob (bincode decoding stays on the host side).  circuit_id: id stored in the container (0 = generic;
+ * SPP_CIRCUIT_WITHDRAW when the program has the withdraw circuit's ABI, so that spp_prove_withdraw accepts it). */
+#define SPP_CIRCUIT_ACIR 5
+int spp_circuit_build_acir(const uint8_t* blob, size_t blob_len, int circuit_id, const char* out_path, uint32_t* n_constraints);
+
 /* ---- device context ---- */
 int spp_init(int device, spp_ctx** out);
 void spp_free_ctx(spp_ctx* ctx);

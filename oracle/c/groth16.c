@@ -21,7 +21,7 @@
 /* ------------------------------------------------------------------------------------------------ */
 /* circuit container                                                                                 */
 /* ------------------------------------------------------------------------------------------------ */
-enum { OP_END, OP_SOLVE_C, OP_SOLVE_A, OP_BATCH_DIV, OP_BITS, OP_LIMBS8, OP_COUNT8, OP_POSEIDON, OP_POSEIDON2, OP_COMMIT, OP_GRUMPKIN };
+enum { OP_END, OP_SOLVE_C, OP_SOLVE_A, OP_BATCH_DIV, OP_BITS, OP_LIMBS8, OP_COUNT8, OP_POSEIDON, OP_POSEIDON2, OP_COMMIT, OP_GRUMPKIN, OP_INV_H };
 
 typedef struct { uint32_t rows, nnz; uint32_t* rowptr; uint32_t* wire; uint32_t* coeff; } sparse_t;
 typedef struct {
@@ -339,6 +339,15 @@ static int solve(const circuit_t* c, fe* w, challenge_fn chal, void* chal_ctx) {
         row_dot(&v, c, &c->H, h, w);
         fe_to_raw(raw, &v, &FR);
         for (uint32_t i = 0; i < nb; i++) fe_from_u64(&w[out0 + i], (raw[i / 64] >> (i % 64)) & 1, &FR);
+        break;
+      }
+      case OP_INV_H: {   /* unconstrained inverse hint: 1 / <H_h,w>, 0 for 0 */
+        uint32_t h = pr[pc + 1], out = pr[pc + 2];
+        pc += 3;
+        fe v;
+        row_dot(&v, c, &c->H, h, w);
+        if (fe_is_zero(&v)) memset(&w[out], 0, sizeof(fe));
+        else fe_inv(&w[out], &v, &FR);
         break;
       }
       case OP_LIMBS8: {

@@ -11,7 +11,7 @@ import struct
 from .bn254 import R, inv
 from . import hashes
 
-OP_END, OP_SOLVE_C, OP_SOLVE_A, OP_BATCH_DIV, OP_BITS, OP_LIMBS8, OP_COUNT8, OP_POSEIDON, OP_POSEIDON2, OP_COMMIT, OP_GRUMPKIN = range(11)
+OP_END, OP_SOLVE_C, OP_SOLVE_A, OP_BATCH_DIV, OP_BITS, OP_LIMBS8, OP_COUNT8, OP_POSEIDON, OP_POSEIDON2, OP_COMMIT, OP_GRUMPKIN, OP_INV_H = range(12)
 
 
 class Sparse:
@@ -209,6 +209,11 @@ def solve(circ, inputs, challenge_fn):
                 den = (s_pt[0] - acc[0]) % R
                 w[lam_wires[j]] = (s_pt[1] - acc[1]) * inv(den, R) % R if den else 0
                 acc = hashes.grumpkin_add(acc, s_pt)
+        elif op == OP_INV_H:
+            h, out = prog[pc + 1:pc + 3]
+            pc += 3
+            v = _dot(circ.H, h, w)
+            w[out] = inv(v, R) if v else 0
         elif op == OP_COMMIT:
             pc += 1
             w[circ.challenge_wire] = challenge_fn(w) % R

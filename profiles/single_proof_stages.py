@@ -1,0 +1,25 @@
+import json, os, sys, tempfile, time
+ROOT="/root/repo"; sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "shielded-pool-pinocchio-solana_amd"))
+import torch, spp
+from spp import workload
+dev=torch.device("cuda",0)
+tmp=tempfile.mkdtemp()
+pk=json.load(open(os.path.join(ROOT,"tests/golden/rlwe_pk.json")))
+for cid,name in ((1,"withdraw"),(2,"audit")):
+    sppc,pkp,vkp=(os.path.join(tmp,name+e) for e in (".sppc",".pk",".vk"))
+    spp.build_circuit(cid,sppc,aux=(list(pk["a"])+list(pk["b"])) if cid==2 else None)
+    ctx=spp.Context(0); ctx.setup(sppc,b"\x2a"*32,pkp,vkp)
+    for win in (8,0):
+        t0=time.time(); h=ctx.load_circuit(sppc,pkp,win); load=time.time()-t0
+        rows=workload.withdraw_rows(ctx,1) if cid==1 else workload.audit_rows(ctx,pk["a"],pk["b"],1)
+        inp=torch.frombuffer(bytearray(rows),dtype=torch.uint8).to(dev)
+        rs=torch.frombuffer(bytearray((5).to_bytes(32,"big")+(6).to_bytes(32,"big")),dtype=torch.uint8).to(dev)
+        pr=torch.zeros(388,dtype=torch.uint8,device=dev); pw=torch.zeros(h.pw_len,dtype=torch.uint8,device=dev); st=torch.zeros(1,dtype=torch.int32,device=dev)
+        lat=[]
+        for _ in range(8):
+            torch.cuda.synchronize(); t=time.perf_counter()
+            h.prove_batch_device(1,inp.data_ptr(),rs.data_ptr(),pr.data_ptr(),pw.data_ptr(),st.data_ptr()); h.sync()
+            lat.append((time.perf_counter()-t)*1e3)
+        print(name,"window",win,"load_s",round(load,2),"lat_ms",round(sorted(lat)[len(lat)//2],2),"stages",[round(x,2) for x in h.last_timings(0)[:7]],"msm",[round(x,3) for x in h.msm_kernel_ms(0)], flush=True)
+        h.close()
+    ctx.close()

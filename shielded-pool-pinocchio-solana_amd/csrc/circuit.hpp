@@ -37,9 +37,10 @@ enum : uint32_t {
   OP_POSEIDON2 = 8,   // h0 out0      : native Poseidon2 t=4 permutation, same wire convention
   OP_COMMIT = 9,      //              : phase boundary: the challenge wire is filled in before continuing
   OP_GRUMPKIN = 10,   // bit0 nbits aux_off n  w_0..w_{n-1} : slopes of the fixed-base Grumpkin ladder (see circuit.cpp)
+  OP_INV_H = 11,      // h out        : w[out] = 1 / <H_h,w>  (0 when the form is 0); an UNCONSTRAINED hint (ACIR Brillig inverse)
 };
 
-enum : uint32_t { CIRCUIT_WITHDRAW = 1, CIRCUIT_AUDIT = 2 };
+enum : uint32_t { CIRCUIT_WITHDRAW = 1, CIRCUIT_AUDIT = 2, CIRCUIT_ACIR = 5 };
 
 struct Term {
   uint32_t wire;
@@ -179,6 +180,34 @@ class Builder {
     push_row(c_.H, a);
     return c_.H.rows() - 1;
   }
+  // unconstrained hints (what ACIR's Brillig calls are): fresh wires filled by the solver, bound only by later constraints
+  LC inv_hint(const LC& a) {
+    uint32_t h = hint_row(a), out = new_wire();
+    c_.program.push_back(OP_INV_H);
+    c_.program.push_back(h);
+    c_.program.push_back(out);
+    return LC::wire(out);
+  }
+  std::vector<LC> bits_hint(const LC& a, uint32_t nbits) {
+    uint32_t h = hint_row(a), out0 = next_wire_;
+    c_.program.push_back(OP_BITS);
+    c_.program.push_back(h);
+    c_.program.push_back(nbits);
+    c_.program.push_back(out0);
+    std::vector<LC> bits;
+    for (uint32_t i = 0; i < nbits; i++) bits.push_back(LC::wire(new_wire()));
+    return bits;
+  }
+  std::vector<LC> limbs8_hint(const LC& a, uint32_t n) {
+    uint32_t h = hint_row(a), out0 = next_wire_;
+    c_.program.push_back(OP_LIMBS8);
+    c_.program.push_back(h);
+    c_.program.push_back(n);
+    c_.program.push_back(out0);
+    std::vector<LC> limbs;
+    for (uint32_t i = 0; i < n; i++) limbs.push_back(LC::wire(new_wire()));
+    return limbs;
+  }
 
   // little-endian bits of a (nbits), each constrained boolean, recomposition asserted
   std::vector<LC> to_bits(const LC& a, uint32_t nbits) {
@@ -315,6 +344,10 @@ std::pair<LC, LC> gadget_grumpkin_fixed_base(Builder& b, const std::vector<LC>& 
 GkAffine grumpkin_generator();
 GkAffine grumpkin_offset();
 Circuit build_withdraw_circuit(bool native_hints, uint32_t pad_to_constraints = 0, uint32_t depth = 16);
+// Compiles a decoded ACIR program (spp/acir.py to_blob: AssertZero / RANGE / fixed-base Grumpkin MSM / Brillig hints) into an
+// R1CS + solver program: the `sunspot compile <acir>` step (noir_circuit/prove_linux.sh:66-70) for nargo-compiled circuits.
+// Returns false and sets *err on an unsupported construct.  csrc/circuit_acir.cpp
+bool build_acir_circuit(const uint8_t* blob, size_t len, uint32_t circuit_id, Circuit* out, std::string* err);
 Circuit build_audit_circuit(const uint32_t* pk_a, const uint32_t* pk_b, bool native_hints);
 
 }  // namespace spp

@@ -281,6 +281,13 @@ __global__ void __launch_bounds__(64) k_solve(DevCircuit dc, Fr* __restrict__ W,
         }
         break;
       }
+      case OP_INV_H: {       // unconstrained inverse hint (ACIR Brillig): 1 / <H_h,w>, 0 for 0
+        const uint32_t h = pr[pc + 1], out = pr[pc + 2];
+        pc += 3;
+        Fr v = dev_row_dot(dc.H, dc.coeffs, h, 0, W, P, p);
+        W[(size_t)out * P + p] = v.is_zero() ? Fr::zero() : v.inv();
+        break;
+      }
       case OP_LIMBS8: {
         const uint32_t h = pr[pc + 1], nl = pr[pc + 2], out0 = pr[pc + 3];
         pc += 4;

@@ -211,6 +211,18 @@ extern "C" int spp_circuit_build(int circuit_id, const uint32_t* aux, const char
   return SPP_OK;
 }
 
+// `sunspot compile <acir>` for a nargo-compiled program: blob = spp/acir.py to_blob() (the decoded opcode list)
+extern "C" int spp_circuit_build_acir(const uint8_t* blob, size_t blob_len, int circuit_id, const char* out_path, uint32_t* n_constraints) {
+  if (!blob || !out_path) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  Circuit c;
+  std::string err;
+  if (!build_acir_circuit(blob, blob_len, circuit_id > 0 ? (uint32_t)circuit_id : CIRCUIT_ACIR, &c, &err))
+    return fail(SPP_ERR_FORMAT, "ACIR program not supported: %s", err.c_str());
+  if (n_constraints) *n_constraints = c.n_constraints;
+  if (!c.save(out_path)) return fail(SPP_ERR_IO, "cannot write %s", out_path);
+  return SPP_OK;
+}
+
 // -----------------------------------------------------------------------------------------------------
 // context
 // -----------------------------------------------------------------------------------------------------
@@ -501,7 +513,7 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
           pc += 4;
           break;
         case OP_BITS: case OP_LIMBS8: case OP_POSEIDON: pc += 4; break;
-        case OP_POSEIDON2: pc += 3; break;
+        case OP_POSEIDON2: case OP_INV_H: pc += 3; break;
         case OP_COMMIT:
           flush(pc);
           c->schedule.push_back({SolveStep::COMMIT, 0, 0, 0});

@@ -392,3 +392,83 @@ def execute(program, input_row):
             for x, v in zip(flat_out, _brillig(fid, args, len(flat_out))):
                 w[x] = v % R
     return w
+
+
+# ---- ACIR -> R1CS (`sunspot compile <acir>`): flat opcode blob for csrc/circuit_acir.cpp ----
+def _f32(v):
+    return int(v % R).to_bytes(32, "little")
+
+
+def _expr_bytes(e):
+    out = struct.pack("<I", len(e.mul_terms))
+    for c, a, b in e.mul_terms:
+        out += _f32(c) + struct.pack("<II", a, b)
+    out += struct.pack("<I", len(e.linear))
+    for c, a in e.linear:
+        out += _f32(c) + struct.pack("<I", a)
+    return out + _f32(e.constant)
+
+
+def to_blob(program):
+    """The decoded opcode list in the flat layout csrc/circuit_acir.cpp reads (see its header).  Brillig calls are classified by
+    their call shape -- the functions themselves are unconstrained helpers whose outputs the following opcodes constrain:
+      (expr, constant power of two) -> (q, r)            quotient / remainder    (field -> 128-bit limbs)
+      (expr) -> (x)                                       inverse, 0 for 0        (is-zero / != gadgets)
+      (expr, constant n, constant 2) -> [n witnesses]     little-endian bits      (index -> path bits)
+    and MultiScalarMul must be over the Grumpkin generator with an always-true predicate (fixed_base_scalar_mul).
+    Anything else raises AcirFormatError."""
+    c = program.main
+    pub, sec = c.public_parameters, c.private_parameters
+    if pub != list(range(len(pub))) or sec != list(range(len(pub), len(pub) + len(sec))):
+        raise AcirFormatError("parameters must occupy witnesses 0..n-1, public ones first")
+    if c.return_values:
+        raise AcirFormatError("return values are not supported")
+    ops = []
+    for i, op in enumerate(c.opcodes):
+        k = op[0]
+        if k == "AssertZero":
+            ops.append(struct.pack("<I", 0) + _expr_bytes(op[1]))
+        elif k == "RANGE":
+            _, (t, w), bits = op
+            if t != "witness":
+                raise AcirFormatError("opcode %d: RANGE on a constant" % i)
+            ops.append(struct.pack("<III", 1, w, bits))
+        elif k == "MultiScalarMul":
+            _, points, scalars, predicate, outs = op
+            if points != [("constant", _GK_GEN[0]), ("constant", _GK_GEN[1]), ("constant", 0)] or predicate != ("constant", 1) \
+                    or len(scalars) != 2 or any(t != "witness" for t, _ in scalars):
+                raise AcirFormatError("opcode %d: only fixed-base MultiScalarMul over the Grumpkin generator is supported" % i)
+            ops.append(struct.pack("<IIIIII", 2, scalars[0][1], scalars[1][1], outs[0], outs[1], outs[2]))
+        elif k == "BrilligCall":
+            _, fid, inputs, outputs, predicate = op
+            if predicate is not None or any(t != "single" for t, _ in inputs):
+                raise AcirFormatError("opcode %d: predicated / array-input Brillig calls are not supported" % i)
+            exprs = [e for _, e in inputs]
+            const = lambda e: not e.mul_terms and not e.linear
+            shape = (len(exprs), [o[0] for o in outputs])
+            if shape == (2, ["simple", "simple"]) and const(exprs[1]) and exprs[1].constant and exprs[1].constant & (exprs[1].constant - 1) == 0:
+                ops.append(struct.pack("<I", 3) + _expr_bytes(exprs[0]) + struct.pack("<III", exprs[1].constant.bit_length() - 1, outputs[0][1], outputs[1][1]))
+            elif shape == (1, ["simple"]):
+                ops.append(struct.pack("<I", 4) + _expr_bytes(exprs[0]) + struct.pack("<I", outputs[0][1]))
+            elif shape == (3, ["array"]) and const(exprs[1]) and const(exprs[2]) and exprs[2].constant == 2 and exprs[1].constant == len(outputs[0][1]):
+                outs = outputs[0][1]
+                ops.append(struct.pack("<I", 5) + _expr_bytes(exprs[0]) + struct.pack("<I%dI" % len(outs), len(outs), *outs))
+            else:
+                raise AcirFormatError("opcode %d: Brillig call %d has an unrecognised shape" % (i, fid))
+        else:
+            raise AcirFormatError("opcode %d: %s is not supported" % (i, k))
+    return struct.pack("<IIII", 0x31524341, len(pub), len(sec), len(ops)) + b"".join(ops)
+
+
+def compile_to_sppc(program_or_path, out_path, circuit_id=None):
+    """`sunspot compile <acir>`: writes the SPPC container for the program, returns nbConstraints.  circuit_id defaults to
+    SPP_CIRCUIT_WITHDRAW when the program has the withdraw circuit's ABI (5 public + 21 private inputs), else the generic id."""
+    import ctypes
+    from .lib import load_library, check
+    prog = program_or_path if isinstance(program_or_path, Program) else load_program(program_or_path)
+    blob = to_blob(prog)
+    if circuit_id is None:
+        circuit_id = 1 if (len(prog.main.public_parameters), len(prog.main.private_parameters)) == (5, 21) else 5
+    n = ctypes.c_uint32(0)
+    check(load_library().spp_circuit_build_acir(blob, len(blob), int(circuit_id), out_path.encode(), ctypes.byref(n)))
+    return n.value

@@ -2,6 +2,8 @@
 output-file naming (outputs land next to the circuit file, as sunspot writes them next to the .ccs).
 
     python -m spp.cli compile withdraw|audit [--rlwe-pk rlwe_pk.json] -o target/<name>.sppc     # prints nbConstraints=<n>
+    python -m spp.cli compile target/<name>.json [-o target/<name>.sppc]                          # sunspot compile <acir>: the
+                                                                                                  # nargo-compiled program itself
     python -m spp.cli setup   target/<name>.sppc [--seed HEX32] [--force]                         # -> <name>.pk, <name>.vk (+ .setup.json;
                                                                                                   #    skipped when the keys match the circuit)
     python -m spp.cli prove   target/<name>.sppc target/<name>.pk Prover.toml                    # -> <name>.proof, <name>.pw
@@ -59,7 +61,8 @@ def input_vector(vals):
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="spp")
     sub = ap.add_subparsers(dest="cmd", required=True)
-    c = sub.add_parser("compile"); c.add_argument("circuit", choices=["withdraw", "audit"]); c.add_argument("--rlwe-pk"); c.add_argument("-o", "--out", required=True)
+    c = sub.add_parser("compile"); c.add_argument("circuit", help="withdraw | audit | path of a nargo-compiled target/<name>.json (ACIR)")
+    c.add_argument("--rlwe-pk"); c.add_argument("-o", "--out", default=None)
     s = sub.add_parser("setup"); s.add_argument("sppc"); s.add_argument("--seed", default=None); s.add_argument("--device", type=int, default=0)
     s.add_argument("--force", action="store_true", help="redo the setup even when matching keys exist")
     p = sub.add_parser("prove"); p.add_argument("files", nargs="+", help="<sppc> <pk> <Prover.toml>  |  <acir.json> <witness.gz> <sppc> <pk>")
@@ -69,6 +72,19 @@ def main(argv=None):
     v = sub.add_parser("verify"); v.add_argument("vk"); v.add_argument("proof"); v.add_argument("pw")
     a = ap.parse_args(argv)
     if a.cmd == "compile":
+        if a.circuit not in ("withdraw", "audit"):
+            # `sunspot compile target/<name>.json` (prove_linux.sh:66-70): the reference's own compiled ACIR -> R1CS
+            from . import acir
+            out = a.out or os.path.splitext(a.circuit)[0] + ".sppc"
+            try:
+                n = acir.compile_to_sppc(a.circuit, out)
+            except (acir.AcirFormatError, lib.SppError) as e:
+                print("spp compile: %s" % e, file=sys.stderr)
+                return 1
+            print("nbConstraints=%d" % n)
+            return 0
+        if not a.out:
+            ap.error("-o/--out is required")
         aux = None
         if a.circuit == "audit":
             if not a.rlwe_pk:

@@ -41,6 +41,7 @@ def load_library():
     L.spp_last_error.restype = cp
     L.spp_version.restype = cp
     L.spp_circuit_build.argtypes = [i32, vp, cp, ctypes.POINTER(u32)]
+    L.spp_circuit_build_acir.argtypes = [cp, sz, i32, cp, ctypes.POINTER(u32)]
     L.spp_init.argtypes = [i32, ctypes.POINTER(vp)]
     L.spp_free_ctx.argtypes = [vp]
     L.spp_free_ctx.restype = None
