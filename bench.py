@@ -52,7 +52,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=10)    # SURVEY 8d timing rule: warm-up 3, >= 10 iterations or >= 2 s
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=0, help="proofs per GPU per step in weak mode (0 = 2048 audit / 4096 withdraw)")
-    ap.add_argument("--circuit", default=os.environ.get("SPP_BENCH_CIRCUIT", "audit"), choices=["withdraw", "audit"])
+    ap.add_argument("--circuit", default=os.environ.get("SPP_BENCH_CIRCUIT", "audit"), choices=["withdraw", "audit", "withdraw_acir"])
     ap.add_argument("--mode", default="weak", choices=["weak", "strong"])
     ap.add_argument("--total", type=int, default=1024, help="strong mode: proofs per step over all GPUs (BASELINE.json configs[2]: 1024)")
     ap.add_argument("--window", type=int, default=int(os.environ.get("SPP_WINDOW", "0")), help="MSM window bits; 0 = auto (largest tables within the HBM budget)")

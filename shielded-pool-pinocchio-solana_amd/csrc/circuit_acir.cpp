@@ -27,8 +27,10 @@
 //     bound only by the AssertZero and RANGE opcodes that follow them.
 //   MultiScalarMul(G; lo, hi): the fixed-base Grumpkin ladder of circuit.cpp over the 256 bits of (lo, hi).
 // Builder::finish() adds the lookup argument with its BSB22 commitment, so the 388-byte proof layout is kept.
+#include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
 #include <string>
 #include "circuit.hpp"
 
@@ -86,11 +88,59 @@ struct Compiler {
   bool known(uint32_t w) const { return wmap.count(w) != 0; }
   const LC& val(uint32_t w) { return wmap[w]; }
   // a linear combination that has grown long is pinned to one wire (one row) so that later rows stay short
+  size_t compact_above = 40;
   LC compact(const LC& v) {
-    if (v.t.size() <= 48) return v;
+    if (v.t.size() <= compact_above) return v;
     return b.mul(v, LC::constant(Fr::one()), true, false);
   }
   void define(uint32_t w, const LC& v) { wmap[w] = compact(v); }
+  // Which factor of a product goes to the B side: a wire in B costs a G1 AND a G2 table walk in every proof (the G2 one three
+  // times as expensive), a wire in A one G1 walk -- so the factor that brings fewer NEW wires into B goes there.
+  std::set<uint32_t> b_wires;
+  size_t new_in_b(const LC& v) const {
+    size_t n = 0;
+    for (auto& e : v.t) n += (e.first != 0 && !b_wires.count(e.first)) ? 1 : 0;
+    return n;
+  }
+  void orient(LC& a, LC& bb) {
+    if (new_in_b(a) < new_in_b(bb)) std::swap(a, bb);
+    for (auto& e : bb.t) if (e.first) b_wires.insert(e.first);
+  }
+  // Peephole for power maps (Poseidon's x^5 is compiled by nargo as x2 = x x, x4 = x2 x2, x5 = x4 x): a wire known to be a
+  // square x x that is itself squared is rewritten (x2 x) x -- one more row, but x2 never enters B (see orient), which is
+  // what circuit.cpp's hand-written S-box does.  squares: wire -> the factor x it is the square of.
+  std::map<uint32_t, LC> squares;
+  static bool same(const LC& a, const LC& bb) {
+    if (a.t.size() != bb.t.size()) return false;
+    for (size_t i = 0; i < a.t.size(); i++)
+      if (a.t[i].first != bb.t[i].first || !(a.t[i].second == bb.t[i].second)) return false;
+    return true;
+  }
+  static bool single_wire(const LC& a, uint32_t* w) {
+    if (a.t.size() != 1 || a.t[0].first == 0 || !(a.t[0].second == Fr::one())) return false;
+    *w = a.t[0].first;
+    return true;
+  }
+  // rewrites (a, bb) in place when it is the square of a recorded square; returns true if it did
+  bool peephole = true;
+  bool split_fourth_power(LC& a, LC& bb) {
+    uint32_t w;
+    if (!peephole) return false;
+    if (!same(a, bb) || !single_wire(a, &w)) return false;
+    auto it = squares.find(w);
+    if (it == squares.end()) return false;
+    const LC x = it->second;
+    for (auto& e : x.t) if (e.first) b_wires.insert(e.first);
+    a = b.mul(LC::wire(w), x, true, false);        // x3 = x2 * x   (A = x2, B = x)
+    bb = x;
+    return true;
+  }
+  LC product(const LC& x, const LC& y) {           // helper wire t = x y (folds when a factor is constant)
+    if (x.is_constant() || y.is_constant()) return b.mul(x, y);
+    LC a = x, bb = y;
+    orient(a, bb);
+    return b.mul(a, bb);
+  }
   // value of an expression whose witnesses are all known (products become wires)
   bool expr_value(const Expr& e, LC* out) {
     LC s = LC::constant(e.c);
@@ -100,7 +150,7 @@ struct Compiler {
     }
     for (auto& t : e.mul) {
       if (!known(t.a) || !known(t.b)) { err = "hint input uses an unsolved witness"; return false; }
-      s = s + b.mul(val(t.a), val(t.b)).scaled(t.q);
+      s = s + product(val(t.a), val(t.b)).scaled(t.q);
     }
     *out = s;
     return true;
@@ -139,21 +189,38 @@ struct Compiler {
     }
     if (has_u && u_in_product) {
       // u * (den + qu) = -(rest + plain products)
-      for (auto* t : plain) rest = rest + b.mul(val(t->a), val(t->b)).scaled(t->q);
-      define(u, b.div(rest.neg(), den + LC::constant(qu)));
+      for (auto* t : plain) rest = rest + product(val(t->a), val(t->b)).scaled(t->q);
+      LC d = den + LC::constant(qu);
+      for (auto& e : d.t) if (e.first) b_wires.insert(e.first);
+      define(u, b.div(rest.neg(), d));
       return true;
     }
     // keep ONE plain product for the row, turn the others into helper wires
     const MulTerm* main = plain.empty() ? nullptr : plain.back();
-    for (size_t i = 0; i + 1 < plain.size(); i++) rest = rest + b.mul(val(plain[i]->a), val(plain[i]->b)).scaled(plain[i]->q);
+    for (size_t i = 0; i + 1 < plain.size(); i++) rest = rest + product(val(plain[i]->a), val(plain[i]->b)).scaled(plain[i]->q);
+    LC ma, mb;
+    if (main) {
+      ma = val(main->a);
+      mb = val(main->b);
+      if (ma.is_constant() || mb.is_constant()) {      // a product with a constant factor is linear
+        rest = rest + (ma.is_constant() ? mb.scaled(ma.constant_value()) : ma.scaled(mb.constant_value())).scaled(main->q);
+        main = nullptr;
+      } else if (!split_fourth_power(ma, mb)) {
+        orient(ma, mb);
+      }
+    }
     if (has_u) {
       if (qu.is_zero()) { err = "opcode " + std::to_string(index) + ": unsolved witness with zero coefficient"; return false; }
       const Fr k = qu.inv().neg();                       // u = k * (q a b + rest)
-      if (main) define(u, b.mul_sub(val(main->a).scaled(main->q * k), val(main->b), rest.scaled(k).neg()));
-      else define(u, rest.scaled(k));
+      if (main) {
+        const bool is_square = same(val(main->a), val(main->b)) && same(ma, mb) && rest.t.empty() && (main->q * k == Fr::one());
+        define(u, b.mul_sub(ma.scaled(main->q * k), mb, rest.scaled(k).neg(), true, false));
+        uint32_t w;
+        if (is_square && single_wire(wmap[u], &w)) squares[w] = mb;
+      } else define(u, rest.scaled(k));
       return true;
     }
-    if (main) b.constrain(val(main->a).scaled(main->q), val(main->b), rest.neg());
+    if (main) b.constrain(ma.scaled(main->q), mb, rest.neg());
     else b.constrain(rest, LC::constant(Fr::one()), LC());
     return true;
   }
@@ -195,6 +262,8 @@ bool build_acir_circuit(const uint8_t* blob, size_t len, uint32_t circuit_id, Ci
   const uint32_t n_pub = r.u32(), n_sec = r.u32(), n_ops = r.u32();
   if (!r.ok || n_pub == 0 || n_pub > 64 || n_sec > (1u << 20)) return bail("bad header");
   Compiler c(circuit_id);
+  if (const char* e = getenv("SPP_ACIR_COMPACT")) c.compact_above = (size_t)atoi(e);
+  if (getenv("SPP_ACIR_NO_PEEPHOLE")) c.peephole = false;
   for (uint32_t i = 0; i < n_pub; i++) c.wmap[i] = c.b.public_input();
   for (uint32_t i = 0; i < n_sec; i++) c.wmap[n_pub + i] = c.b.secret_input();
   for (uint32_t k = 0; k < n_ops; k++) {
