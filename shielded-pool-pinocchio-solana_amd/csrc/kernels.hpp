@@ -35,6 +35,10 @@ struct DevCircuit {
   // constraints of a Poseidon S-box share B = the S-box input): run r covers rows run_start[r] .. run_start[r+1]-1
   const uint32_t* run_start;
   uint32_t n_runs;
+  // solver shortcuts per constraint: bit 0 = the B row is identical to the B row of constraint k - 1, bit 1 = the A row is
+  // identical to the B row (a square).  A solver lane that has just evaluated row k - 1 reuses the value instead of walking
+  // the same linear form again: the rows of a power map share their B side, and compiled (ACIR) circuits have long forms.
+  const uint8_t* row_flags;
   // hash constants (Montgomery)
   const Fr* pos3_rc;  const Fr* pos3_mds;   // t=3: 195 rc, 9 mds (row-major)
   const Fr* pos5_rc;  const Fr* pos5_mds;   // t=5: 340 rc, 25 mds

@@ -238,6 +238,8 @@ __global__ void __launch_bounds__(64) k_solve(DevCircuit dc, Fr* __restrict__ W,
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
   const uint32_t* __restrict__ pr = dc.program;
+  uint32_t last_k = 0xffffffffu;      // constraint whose B value is cached in last_b (dc.row_flags)
+  Fr last_b = Fr::zero();
   while (pc < pc_end) {
     const uint32_t op = pr[pc];
     if (op == OP_END || op == OP_COMMIT) break;
@@ -245,8 +247,11 @@ __global__ void __launch_bounds__(64) k_solve(DevCircuit dc, Fr* __restrict__ W,
       case OP_SOLVE_C: {
         const uint32_t k = pr[pc + 1];
         pc += 2;
-        Fr a = dev_row_dot(dc.A, dc.coeffs, k, 0, W, P, p);
-        Fr b = dev_row_dot(dc.B, dc.coeffs, k, 0, W, P, p);
+        const uint32_t fl = dc.row_flags[k];
+        Fr b = ((fl & 1) && last_k + 1 == k) ? last_b : dev_row_dot(dc.B, dc.coeffs, k, 0, W, P, p);
+        Fr a = (fl & 2) ? b : dev_row_dot(dc.A, dc.coeffs, k, 0, W, P, p);
+        last_k = k;
+        last_b = b;
         Fr rest = dev_row_dot(dc.C, dc.coeffs, k, 1, W, P, p);
         const uint32_t out = dc.C.wire[dc.C.rowptr[k + 1] - 1];
         W[(size_t)out * P + p] = a * b - rest;

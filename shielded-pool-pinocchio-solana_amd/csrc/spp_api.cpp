@@ -443,6 +443,18 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
     if ((e = own_upload(c, &d_runs, runs))) return e;
     c->dc.run_start = d_runs;
     c->dc.n_runs = n_runs;
+    std::vector<uint8_t> flags(std::max<uint32_t>(circ.n_constraints, 1), 0);
+    for (uint32_t k = 0; k < circ.n_constraints; k++) {
+      if (k > 0 && same_b(k)) flags[k] |= 1;
+      const uint32_t a0 = circ.A.rowptr[k], a1 = circ.A.rowptr[k + 1], b0 = circ.B.rowptr[k], b1 = circ.B.rowptr[k + 1];
+      bool eq = a1 - a0 == b1 - b0 && a1 != a0;
+      for (uint32_t t = 0; eq && t < a1 - a0; t++)
+        eq = circ.A.terms[a0 + t].wire == circ.B.terms[b0 + t].wire && circ.A.terms[a0 + t].coeff == circ.B.terms[b0 + t].coeff;
+      if (eq) flags[k] |= 2;
+    }
+    uint8_t* d_flags;
+    if ((e = own_upload(c, &d_flags, flags))) return e;
+    c->dc.row_flags = d_flags;
   }
   c->dc.n_public = circ.n_public;
   c->dc.n_inputs = circ.n_inputs();
