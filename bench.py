@@ -227,7 +227,13 @@ def main():
     dry = os.environ.get("SPP_BENCH_DRYRUN") == "1"
     if "SPP_FORCE_DEVICE" in os.environ:
         local_rank = int(os.environ["SPP_FORCE_DEVICE"])
-    if world > 1:
+    # SPP_BENCH_FORCE_DIST=1: create the process group even for one rank (exercises the RCCL path -- rendezvous, key broadcast,
+    # barriers, the MAX / SUM reductions -- on a single-GPU box)
+    if world > 1 or os.environ.get("SPP_BENCH_FORCE_DIST") == "1":
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist_mod
         dist = dist_mod
         if backend == "nccl":
@@ -267,7 +273,7 @@ def main():
         if rank == 0:
             ctx.setup(sppc, b"\x2a" * 32, pkp, vkp)
         setup_s = time.time() - t0
-        if world > 1:
+        if dist is not None:
             torch.cuda.synchronize()
             dist.barrier()
             tb = time.time()
@@ -452,7 +458,7 @@ def main():
                        "circuit": circuit, "n_constraints": h.n_constraints, "n_wires": h.n_wires, "domain": 1 << h.domain_log,
                        "batch_per_gpu": B, "n_distinct_witnesses": n_distinct, "proofs_per_step_all_gpus": total_proofs,
                        "msm_windows": windows, "msm_sizes": sizes, "table_bytes": h.table_bytes, "parallelism": "independent proofs x%d" % world,
-                       "pk_bcast_ms": round(bcast_ms, 3), "pk_bytes": pk_bytes, "setup_s": round(setup_s, 2), "load_s": round(load_s, 2),
+                       "pk_bcast_ms": round(bcast_ms, 3), "pk_bcast_backend": (backend if dist is not None else None), "pk_bytes": pk_bytes, "setup_s": round(setup_s, 2), "load_s": round(load_s, 2),
                        "rows_synth_s": round(rows_s, 2), "host_buffer_entry_proofs_per_s": None if host_rate is None else round(host_rate, 1),
                        "last_timed_batch_verified": "all %d proofs accepted by spp_verify_batch (GPU), two of them also by spp_verify (host)" % B,
                        "host_buffer_entry_note": "one spp_prove_batch call with host pointers for 4 batches' worth of proofs: PCIe copies included, chunks pipelined inside libspp"},

@@ -565,6 +565,53 @@ def test_rlwe_witness_random_batch_and_edges(ctx, rlwe_pk):
         assert out["c0_packed"][i] == rlwe.pack_values(c0) and out["c1_packed"][i] == rlwe.pack_values(c1)
 
 
+def test_rlwe_witness_degenerate_public_keys(ctx, rlwe_pk):
+    """Public keys the NTT kernel treats specially: zero coefficients (the reference's matrix rows hold 0, not q, in the wrapped
+    positions: the zero-list correction of rlwe_ntt.hpp), the all-zero key, the identity key a = [1, 0, ...], the largest
+    coefficients q - 1, and alternating extreme r -- all against the oracle's schoolbook restatement (generate_audit.py:45-66,
+    236-243), plus linearity of c1 in r modulo q at a larger batch."""
+    import numpy as np
+    from spp import witness
+    from oracle import rlwe
+    q = rlwe.RLWE_Q
+    rng = np.random.default_rng(9)
+    a0 = np.array(rlwe_pk["a"], dtype=np.int64)
+    b0 = np.array(rlwe_pk["b"], dtype=np.int64)
+    keys = []
+    a = a0.copy(); a[[0, 1, 500, 1023]] = 0; b = b0.copy(); b[[3, 63, 64, 700]] = 0
+    keys.append((a, b))                                                       # a few zeros in both polynomials
+    keys.append((np.zeros(1024, dtype=np.int64), np.zeros(1024, dtype=np.int64)))
+    ident = np.zeros(1024, dtype=np.int64); ident[0] = 1
+    keys.append((ident, np.full(1024, q - 1, dtype=np.int64)))
+    half = a0.copy(); half[::2] = 0
+    keys.append((half, b0))                                                   # 512 zeros
+    count = 6
+    r = rng.integers(-3, 4, size=(count, 1024), dtype=np.int8)
+    e1 = rng.integers(-3, 4, size=(count, 64), dtype=np.int8)
+    e2 = rng.integers(-3, 4, size=(count, 1024), dtype=np.int8)
+    msg = rng.integers(0, 256, size=(count, 64), dtype=np.uint8)
+    r[0, ::2] = 127; r[0, 1::2] = -128
+    r[1] = -128; e2[1] = 127; msg[1] = 255; e1[1] = 127
+    for a, b in keys:
+        out = witness.rlwe_witness(ctx, a.tolist(), b.tolist(), r, e1, e2, msg)
+        for i in range(count):
+            c0, c1, k0, k1 = rlwe.rlwe_witness(a.tolist(), b.tolist(), r[i].tolist(), e1[i].tolist(), e2[i].tolist(), msg[i].tolist())
+            assert out["c0"][i].tolist() == c0 and out["c1"][i].tolist() == c1, i
+            assert out["k0"][i].tolist() == k0 and out["k1"][i].tolist() == k1, i
+    # size-independent property at a larger batch: c1(r + r') = c1(r) + c1(r') - e2-terms, modulo q (zero noise)
+    n = 3000
+    r1 = rng.integers(-60, 61, size=(n, 1024), dtype=np.int8)
+    r2 = rng.integers(-60, 61, size=(n, 1024), dtype=np.int8)
+    z1 = np.zeros((n, 64), dtype=np.int8); z2 = np.zeros((n, 1024), dtype=np.int8); zm = np.zeros((n, 64), dtype=np.uint8)
+    o1 = witness.rlwe_witness(ctx, rlwe_pk["a"], rlwe_pk["b"], r1, z1, z2, zm)
+    o2 = witness.rlwe_witness(ctx, rlwe_pk["a"], rlwe_pk["b"], r2, z1, z2, zm)
+    o3 = witness.rlwe_witness(ctx, rlwe_pk["a"], rlwe_pk["b"], (r1 + r2).astype(np.int8), z1, z2, zm)
+    assert ((o1["c1"].astype(np.int64) + o2["c1"]) % q == o3["c1"]).all() and ((o1["c0"].astype(np.int64) + o2["c0"]) % q == o3["c0"]).all()
+    # the integer identity behind the quotient: sum over the three runs of (k q + c) is additive too
+    s1 = o1["k1"].astype(np.int64) * q + o1["c1"]; s2 = o2["k1"].astype(np.int64) * q + o2["c1"]; s3 = o3["k1"].astype(np.int64) * q + o3["c1"]
+    assert (s1 + s2 == s3).all()
+
+
 def test_poseidon_merkle_grumpkin_kernels(ctx, withdraw_kat):
     from spp import witness
     from oracle import hashes as H

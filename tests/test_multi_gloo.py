@@ -86,3 +86,40 @@ def test_bench_under_an_external_launcher():
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     assert json.loads(lines[0])["n_gpus"] == 2
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_strong_mode_on_one_gpu(tmp_path):
+    """The N > 1 path of bench.py with real proving: two rank processes started by bench.py itself, gloo for the collectives
+    (both ranks sit on the one GPU of the box, which RCCL refuses), each proving its contiguous block of a fixed 64-proof audit
+    batch with small tables; one line, n_gpus = 2, scaling = strong."""
+    import json
+    import subprocess
+    env = dict(os.environ, SPP_BENCH_BACKEND="gloo", SPP_FORCE_DEVICE="0", SPP_TABLE_BUDGET_GB="40")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--mode", "strong", "--total", "64",
+                          "--no-host-leg"], env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["proofs_per_step_all_gpus"] == 64 and j["config"]["batch_per_gpu"] == 32
+    assert j["config"]["pk_bcast_ms"] > 0 and j["config"]["circuit"] == "audit" and j["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_single_rank_over_rccl(tmp_path):
+    """RCCL itself (backend nccl) with one rank: rendezvous, the key broadcast, barriers and the reductions of bench.py run on
+    the GPU through RCCL -- the multi-rank code path minus the peers, which a one-GPU box cannot supply."""
+    import json
+    import subprocess
+    env = dict(os.environ, SPP_BENCH_FORCE_DIST="1", SPP_TABLE_BUDGET_GB="40", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "64", "--circuit", "withdraw",
+                          "--no-extras", "--no-cpu-baseline", "--no-single", "--no-host-leg"], env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert j["n_gpus"] == 1 and j["config"]["pk_bcast_backend"] == "nccl" and j["config"]["pk_bcast_ms"] > 0
