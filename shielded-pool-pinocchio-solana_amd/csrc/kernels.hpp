@@ -120,7 +120,9 @@ void launch_spmv_check(hipStream_t st, DevCircuit dc, const Fr* W, Fr* abc, uint
 
 // ---- NTT / QAP ----
 // in-place radix-2 passes over data [n][P]; dif: natural->bitreversed with table tw (w^-k or w^k), else DIT
-void launch_ntt(hipStream_t st, Fr* data, uint32_t logn, uint32_t P, const Fr* tw, bool dif, uint32_t nbatch, size_t batch_stride);
+// post (optional): n row factors multiplied into the output rows by the last pass (fused coset shift)
+void launch_ntt(hipStream_t st, Fr* data, uint32_t logn, uint32_t P, const Fr* tw, bool dif, uint32_t nbatch, size_t batch_stride,
+                const Fr* post = nullptr);
 void launch_scale_rows(hipStream_t st, Fr* data, const Fr* table, uint32_t n, uint32_t P, uint32_t nbatch, size_t batch_stride);
 void launch_qap_pointwise(hipStream_t st, Fr* abc, uint32_t n, uint32_t P, Fr zinv);
 

@@ -16,7 +16,7 @@ static constexpr uint32_t NTT_THREADS = 256;
 
 template <bool DIF>
 __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(Fr* __restrict__ data, uint32_t logn, uint32_t P, const Fr* __restrict__ tw,
-                                                          uint32_t s_lo, uint32_t s_hi, size_t batch_stride) {
+                                                          uint32_t s_lo, uint32_t s_hi, size_t batch_stride, const Fr* __restrict__ post) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   Fr* sh = reinterpret_cast<Fr*>(smem_raw);
   data += (size_t)blockIdx.y * batch_stride;
@@ -65,8 +65,14 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(Fr* __restrict__ data,
         }
       __syncthreads();
     }
-    if (valid)
-      for (uint32_t j = jr; j < G; j += jstep) ptr[(uint64_t)j * Cq] = sh[j * T + tc];
+    if (valid) {
+      if (post) {   // fused row scaling (coset shift): element row = bh*G*stride + j*stride + base_low
+        const uint32_t row0 = (uint32_t)(bh * G) * stride + base_low;
+        for (uint32_t j = jr; j < G; j += jstep) ptr[(uint64_t)j * Cq] = sh[j * T + tc] * post[row0 + j * stride];
+      } else {
+        for (uint32_t j = jr; j < G; j += jstep) ptr[(uint64_t)j * Cq] = sh[j * T + tc];
+      }
+    }
     return;
   }
 
@@ -117,12 +123,17 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(Fr* __restrict__ data,
     uint64_t col = col0 + tc;
     if (col < ncols) {
       uint64_t bh = col / Cq, q = col % Cq;
-      data[bh * G * Cq + (uint64_t)j * Cq + q] = sh[j * T + tc];
+      Fr v = sh[j * T + tc];
+      if (post) v = v * post[(uint32_t)(bh * G) * stride + j * stride + (uint32_t)(q / P)];
+      data[bh * G * Cq + (uint64_t)j * Cq + q] = v;
     }
   }
 }
 
-void launch_ntt(hipStream_t st, Fr* data, uint32_t logn, uint32_t P, const Fr* tw, bool dif, uint32_t nbatch, size_t batch_stride) {
+// post (optional): table of n row factors applied to the OUTPUT rows (data[i][p] *= post[i]) while the last pass stores them --
+// the coset shifts of computeH, which used to be separate full read + write passes over the arrays (k_scale_rows)
+void launch_ntt(hipStream_t st, Fr* data, uint32_t logn, uint32_t P, const Fr* tw, bool dif, uint32_t nbatch, size_t batch_stride,
+                const Fr* post) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)k_ntt_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NTT_TILE_ELEMS * sizeof(Fr)));
@@ -138,9 +149,11 @@ void launch_ntt(hipStream_t st, Fr* data, uint32_t logn, uint32_t P, const Fr* t
     dim3 grid((uint32_t)((ncols + T - 1) / T), nbatch);
     size_t shmem = (size_t)NTT_TILE_ELEMS * sizeof(Fr);
     if (dif)
-      hipLaunchKernelGGL(k_ntt_pass<true>, grid, dim3(NTT_THREADS), shmem, st, data, logn, P, tw, s, s + lg, batch_stride);
+      hipLaunchKernelGGL(k_ntt_pass<true>, grid, dim3(NTT_THREADS), shmem, st, data, logn, P, tw, s, s + lg, batch_stride,
+                         ps + 1 == npass ? post : (const Fr*)nullptr);
     else
-      hipLaunchKernelGGL(k_ntt_pass<false>, grid, dim3(NTT_THREADS), shmem, st, data, logn, P, tw, s, s + lg, batch_stride);
+      hipLaunchKernelGGL(k_ntt_pass<false>, grid, dim3(NTT_THREADS), shmem, st, data, logn, P, tw, s, s + lg, batch_stride,
+                         ps + 1 == npass ? post : (const Fr*)nullptr);
     s += lg;
   }
 }

@@ -771,12 +771,11 @@ static int prove_on_device(spp_circuit* c, Workspace& w, uint32_t P, const uint8
   hipEventRecord(w.ev[2], st);
   // 3. h = (a*b - c)/Z  (coefficients land bit-reversed in the a-slot of abc)
   const size_t bs = (size_t)n * P;
-  launch_ntt(st, w.abc, c->logn, P, c->tw_inv, true, 3, bs);
-  launch_scale_rows(st, w.abc, c->coset_br, n, P, 3, bs);
+  // the coset shifts ride on the stores of the inverse transforms' last pass (no separate pass over the arrays)
+  launch_ntt(st, w.abc, c->logn, P, c->tw_inv, true, 3, bs, c->coset_br);
   launch_ntt(st, w.abc, c->logn, P, c->tw_fwd, false, 3, bs);
   launch_qap_pointwise(st, w.abc, n, P, c->zinv);
-  launch_ntt(st, w.abc, c->logn, P, c->tw_inv, true, 1, bs);
-  launch_scale_rows(st, w.abc, c->coset_inv_br, n, P, 1, bs);
+  launch_ntt(st, w.abc, c->logn, P, c->tw_inv, true, 1, bs, c->coset_inv_br);
   hipEventRecord(w.ev[3], st);
   // 4. MSMs
   run_msm(c, w, c->A, w.A, P, true);
