@@ -106,6 +106,15 @@ void launch_load_inputs(hipStream_t st, const uint8_t* d_inputs_be, const uint8_
 // runs the solver program from word `pc` until OP_COMMIT / OP_END; scratch: [SOLVE_SCRATCH_ROWS or more][P] Fr
 static constexpr uint32_t SOLVE_SCRATCH_MIN_ROWS = 324;
 void launch_solve(hipStream_t st, DevCircuit dc, Fr* W, Fr* scratch, uint32_t pc_begin, uint32_t pc_end, uint32_t P);
+// cooperative solver for small batches (one wave per proof; kernels_solve.hip): items = (kind, a, b) triples
+enum : uint32_t { COOP_SEQ = 0, COOP_PAR = 1, COOP_LEVELS = 2, COOP_POSEIDON = 3, COOP_POSEIDON2 = 4 };
+struct DevCoop {
+  const uint32_t* items;      // 3 words per item
+  const uint32_t* par;        // COOP_PAR: (pc_begin, pc_end) pairs of independent instructions
+  const uint32_t* lvl_ptr;    // COOP_LEVELS: rows lvl_rows[lvl_ptr[l] .. lvl_ptr[l+1]) form dependency level l
+  const uint32_t* lvl_rows;
+};
+void launch_solve_coop(hipStream_t st, DevCircuit dc, DevCoop co, Fr* W, Fr* scratch, uint32_t item_begin, uint32_t item_end, uint32_t P);
 // wide forms of the two data-parallel solver instructions (one lane per (element chunk, proof) instead of one per proof)
 void launch_batch_div(hipStream_t st, DevCircuit dc, Fr* W, Fr* scratch, uint32_t k0, uint32_t n, uint32_t P);
 void launch_count8(hipStream_t st, DevCircuit dc, Fr* W, uint32_t* counters, uint32_t h0, uint32_t n, uint32_t out0, uint32_t P);
@@ -136,12 +145,14 @@ size_t msm_table_elems(uint32_t N, uint32_t c);
 // lane g -> (slice g / P, proof g % P); partial[S][P]
 template <class F>
 void launch_msm_accumulate(hipStream_t st, const Affine<F>* table, const uint32_t* rows, const Fr* scalars, XYZZ<F>* partial, uint32_t N,
-                           uint32_t P, uint32_t c, uint32_t S, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                           uint32_t P, uint32_t c, uint32_t S, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, uint32_t Q = 1);
 // out[p] = sum_s partial[s][p]   (S = 0: out[p] = infinity); folds in place: `partial` is scratch afterwards
 template <class F>
 void launch_msm_reduce(hipStream_t st, XYZZ<F>* partial, XYZZ<F>* out, uint32_t P, uint32_t S);
 uint32_t msm_windows(uint32_t c);
 uint32_t msm_slices(uint32_t N, uint32_t P);
+uint32_t msm_window_chunks(uint32_t N, uint32_t P, uint32_t c);   // Q: lanes per base for small batches (1 = none)
+uint32_t msm_slices_split(uint32_t N, uint32_t P, uint32_t Q);
 
 // ---- general-base Pippenger (kernels_pippenger.hip) ----
 size_t pippenger_workspace_bytes(uint32_t n);

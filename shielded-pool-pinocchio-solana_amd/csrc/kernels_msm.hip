@@ -21,6 +21,24 @@ namespace spp {
 
 uint32_t msm_windows(uint32_t c) { return (254 + c - 1) / c; }
 
+// Window chunks per base for small batches (1 = a lane takes whole bases): when 4 bases per slice cannot give ~64K lanes, the
+// windows of a base are split over up to 8 lanes (>= 4 windows each); msm_slices(N * Q', P) lanes then share the items.
+uint32_t msm_window_chunks(uint32_t N, uint32_t P, uint32_t c) {
+  const uint32_t Wn = msm_windows(c);
+  const uint64_t target = 65536;
+  uint32_t Q = 1;
+  while ((uint64_t)((N + 3) / 4) * Q * P < target && Q < 8 && (Wn + 2 * Q - 1) / (2 * Q) >= 4) Q *= 2;
+  return Q;
+}
+uint32_t msm_slices_split(uint32_t N, uint32_t P, uint32_t Q) {
+  if (Q <= 1) return msm_slices(N, P);
+  const uint64_t items = (uint64_t)N * Q;
+  uint64_t S = (65536 + P - 1) / P;
+  if (S > items) S = items;
+  if (S == 0) S = 1;
+  return (uint32_t)S;
+}
+
 // enough (slice, proof) lanes to fill 256 CUs x 4 SIMDs x ~4 waves, but at least 4 bases per slice
 uint32_t msm_slices(uint32_t N, uint32_t P) {
   const uint32_t target_lanes = 256u * 4u * 4u * 64u;
@@ -212,6 +230,46 @@ __global__ void __launch_bounds__(256) k_msm_fixed(const Affine<F>* __restrict__
   partial[(size_t)slice * P + p] = acc.result();
 }
 
+// Small batches (a single proof is the drop-in generateProof case): with one slice per 4 bases a lane walks 4 x Wn windows one
+// after the other -- 128 dependent additions, 0.7 ms per set for one withdraw proof on 32 of the chip's 1024 SIMDs.  Here the work
+// item is (base, chunk of Wq windows): Q = ceil(Wn / Wq) items per base, lane g -> (slice, proof), slice walks items slice,
+// slice + S, ...  The recoder still runs from window 0 (the signed digits carry upwards), a few shifts per skipped window.
+template <class F>
+__global__ void __launch_bounds__(256) k_msm_fixed_split(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ rows,
+                                                         const Fr* __restrict__ scalars, XYZZ<F>* __restrict__ partial, uint32_t N,
+                                                         uint32_t P, uint32_t c, uint32_t Wn, uint32_t S, uint32_t Q, uint32_t Wq) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= S * P) return;
+  const uint32_t p = g % P, slice = g / P;
+  const uint32_t E = 1u << (c - 1);
+  MsmAcc<F> acc;
+  acc.init();
+  const uint32_t items = N * Q;
+  for (uint32_t t = slice; t < items; t += S) {
+    const uint32_t i = t % N, q = t / N;   // chunk-major: the lanes of a wave share q (same skip length, same add phase)
+    Fr s = scalars[(size_t)rows[i] * P + p];
+    if (s.is_zero()) continue;
+    Recoder rc;
+    rc.init(s);
+    const uint32_t j0 = q * Wq, j1 = j0 + Wq < Wn ? j0 + Wq : Wn;
+    // skip phase apart from the add phase: the lanes of a wave hold different chunks q, and an addition inside a loop
+    // whose trip count differs per lane would be executed once per distinct j (a few live lanes each time)
+    bool sgn;
+#pragma unroll 1
+    for (uint32_t j = 0; j < j0; j++) (void)rc.next(c, sgn);
+#pragma unroll 1
+    for (uint32_t j = j0; j < j1; j++) {
+      if (rc.rest_is_zero()) break;
+      uint32_t d = rc.next(c, sgn);
+      if (d != 0) {
+        const uint32_t row = i * Wn + j;
+        acc.madd(table[((size_t)(row >> 6) * E + (d - 1)) * 64 + (row & 63)], sgn);
+      }
+    }
+  }
+  partial[(size_t)slice * P + p] = acc.result();
+}
+
 // fold the S partial sums of every proof: pairwise, one launch per level, every lane busy -- lane (s, p) with s < S_cur - half
 // adds partial[s + half][p] into partial[s][p] (half = ceil(S_cur / 2)); log2(S) launches of S*P/2, S*P/4, ... lanes.  (The
 // first version used one 64-lane block per proof with an LDS tree: most lanes idle, six dependent additions behind barriers;
@@ -239,13 +297,19 @@ __global__ void __launch_bounds__(256) k_msm_fill_inf(XYZZ<F>* __restrict__ out,
 // launch waits for kernels of the other proving stream.
 template <class F>
 void launch_msm_accumulate(hipStream_t st, const Affine<F>* table, const uint32_t* rows, const Fr* scalars, XYZZ<F>* partial, uint32_t N,
-                           uint32_t P, uint32_t c, uint32_t S, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                           uint32_t P, uint32_t c, uint32_t S, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t Q) {
   if (N == 0 || S == 0) {
     if (ev_start) hipEventRecord(ev_start, st);
     if (ev_stop) hipEventRecord(ev_stop, st);
     return;
   }
   uint64_t lanes = (uint64_t)S * P;
+  if (Q > 1) {
+    const uint32_t Wn = msm_windows(c);
+    hipExtLaunchKernelGGL(k_msm_fixed_split<F>, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, st, ev_start, ev_stop, 0, table, rows,
+                          scalars, partial, N, P, c, Wn, S, Q, (Wn + Q - 1) / Q);
+    return;
+  }
   hipExtLaunchKernelGGL(k_msm_fixed<F>, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, st, ev_start, ev_stop, 0, table, rows, scalars,
                         partial, N, P, c, msm_windows(c), S);
 }
@@ -265,9 +329,9 @@ void launch_msm_reduce(hipStream_t st, XYZZ<F>* partial, XYZZ<F>* out, uint32_t 
   } while (cur > 1);
 }
 template void launch_msm_accumulate<Fq>(hipStream_t, const Affine<Fq>*, const uint32_t*, const Fr*, XYZZ<Fq>*, uint32_t, uint32_t, uint32_t,
-                                        uint32_t, hipEvent_t, hipEvent_t);
+                                        uint32_t, hipEvent_t, hipEvent_t, uint32_t);
 template void launch_msm_accumulate<Fq2>(hipStream_t, const Affine<Fq2>*, const uint32_t*, const Fr*, XYZZ<Fq2>*, uint32_t, uint32_t,
-                                         uint32_t, uint32_t, hipEvent_t, hipEvent_t);
+                                         uint32_t, uint32_t, hipEvent_t, hipEvent_t, uint32_t);
 template void launch_msm_reduce<Fq>(hipStream_t, XYZZ<Fq>*, XYZZ<Fq>*, uint32_t, uint32_t);
 template void launch_msm_reduce<Fq2>(hipStream_t, XYZZ<Fq2>*, XYZZ<Fq2>*, uint32_t, uint32_t);
 

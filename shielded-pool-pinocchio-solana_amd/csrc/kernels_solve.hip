@@ -233,10 +233,9 @@ __device__ __noinline__ void dev_grumpkin(const DevCircuit& dc, Fr* __restrict__
   }
 }
 
-__global__ void __launch_bounds__(64) k_solve(DevCircuit dc, Fr* __restrict__ W, Fr* __restrict__ scratch, uint32_t pc, uint32_t pc_end,
-                                              uint32_t P) {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P) return;
+// instructions [pc, pc_end) of the solver program for proof p, one lane
+__device__ __forceinline__ void solve_range(const DevCircuit& dc, Fr* __restrict__ W, Fr* __restrict__ scratch, uint32_t pc, uint32_t pc_end,
+                                            uint32_t P, uint32_t p) {
   const uint32_t* __restrict__ pr = dc.program;
   uint32_t last_k = 0xffffffffu;      // constraint whose B value is cached in last_b (dc.row_flags)
   Fr last_b = Fr::zero();
@@ -359,9 +358,200 @@ __global__ void __launch_bounds__(64) k_solve(DevCircuit dc, Fr* __restrict__ W,
     }
   }
 }
+__global__ void __launch_bounds__(64) k_solve(DevCircuit dc, Fr* __restrict__ W, Fr* __restrict__ scratch, uint32_t pc, uint32_t pc_end,
+                                              uint32_t P) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  solve_range(dc, W, scratch, pc, pc_end, P, p);
+}
 void launch_solve(hipStream_t st, DevCircuit dc, Fr* W, Fr* scratch, uint32_t pc_begin, uint32_t pc_end, uint32_t P) {
   if (pc_begin >= pc_end) return;
   hipLaunchKernelGGL(k_solve, dim3((P + 63) / 64), dim3(64), 0, st, dc, W, scratch, pc_begin, pc_end, P);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// cooperative solver for small batches: one 64-lane wave per proof
+// ---------------------------------------------------------------------------------------------------
+// With one lane per proof a single proof is one lane's serial work: 14 ms for the withdraw circuit, 29 ms for the audit
+// circuit, three quarters of the drop-in generateProof latency, almost all of it inside the hash permutations (a lone wave
+// issues one dependent multiplication after the other on one of the chip's 1024 SIMDs).  Here the 64 lanes of a wave belong
+// to ONE proof and the host-built item list (spp_api.cpp, coop_plan) says how each stretch of the program uses them:
+//   COOP_SEQ       [pc_a, pc_b) on lane 0 (whatever has no parallel form)
+//   COOP_PAR       independent BITS / LIMBS8 / INV_H instructions, one per lane
+//   COOP_LEVELS    a run of SOLVE_C rows in dependency levels: the rows of a level are solved by different lanes
+//   COOP_POSEIDON  one permutation: state words, the two halves of every S-box (x^3 | x^4) and the MDS products on
+//   COOP_POSEIDON2 different lanes -- three dependent multiplications per partial round instead of 13 (t = 3) / 8
+// The values written are the same field elements as the one-lane solver's (the words may be another representative < 2p).
+__device__ __forceinline__ Fr lane_get(const Fr& v, uint32_t src) {
+  Fr r;
+  SPP_UNROLL for (int i = 0; i < 8; i++) r.l[i] = (uint32_t)__shfl((int)v.l[i], (int)src);
+  return r;
+}
+__device__ __forceinline__ Fr lane_sel(bool c, const Fr& a, const Fr& b) {
+  Fr r;
+  SPP_UNROLL for (int i = 0; i < 8; i++) r.l[i] = c ? a.l[i] : b.l[i];
+  return r;
+}
+__device__ __forceinline__ void emit4(Fr* __restrict__ W, uint32_t out, uint32_t P, uint32_t p, const Fr& x2, const Fr& x3, const Fr& x4,
+                                      const Fr& x5) {
+  W[(size_t)out * P + p] = x2;
+  W[(size_t)(out + 1) * P + p] = x3;
+  W[(size_t)(out + 2) * P + p] = x4;
+  W[(size_t)(out + 3) * P + p] = x5;
+}
+
+// Poseidon2 (t = 4): lanes 0..3 hold the state, lanes 4..7 compute x^4 next to x^3 (full rounds); in a partial round lane 4
+// carries mu_0 * x alongside the S-box of lane 0, so that mu_0 * x^5 = (mu_0 * x) * x^4 is ready together with x^5.
+__device__ __noinline__ void coop_poseidon2(const DevCircuit& dc, Fr* __restrict__ W, uint32_t h0, uint32_t out, uint32_t P, uint32_t p,
+                                            uint32_t lane) {
+  const uint32_t l4 = lane & 3;
+  Fr s = Fr::zero();
+  if (lane < 4) s = dev_row_dot(dc.H, dc.coeffs, h0 + lane, 0, W, P, p);
+  const Fr mu = dc.p2_mu[l4];
+  auto external = [&](const Fr& mine) {   // rows (5,7,1,3),(4,6,1,1),(1,3,5,7),(1,1,4,6) of the state held by lanes 0..3
+    const Fr x = lane_get(mine, 0), y = lane_get(mine, 1), z = lane_get(mine, 2), w = lane_get(mine, 3);
+    const Fr t0 = x + y, t1 = z + w, t2 = y.dbl() + t1, t3 = w.dbl() + t0;
+    const Fr t4 = t1.dbl().dbl() + t3, t5 = t0.dbl().dbl() + t2;
+    const Fr t6 = t3 + t5, t7 = t2 + t4;
+    return lane_sel(l4 < 2, lane_sel(l4 == 0, t6, t5), lane_sel(l4 == 2, t7, t4));
+  };
+  s = external(s);
+  uint32_t k = 0;
+  auto full_round = [&]() {
+    const Fr x = s + dc.p2_rc[k + l4];
+    const Fr x2 = x * x;
+    const Fr t = lane_get(x2, l4);                       // lanes 4..7: x^2 of lane - 4
+    const Fr R = t * lane_sel(lane < 4, x, t);           // lanes 0..3: x^3, lanes 4..7: x^4
+    const Fr x4 = lane_get(R, l4 + 4);
+    const Fr x5 = x4 * x;
+    if (lane < 4) emit4(W, out + 4 * lane, P, p, x2, R, x4, x5);
+    out += 16;
+    k += 4;
+    s = external(x5);
+  };
+#pragma unroll 1
+  for (int r = 0; r < 4; r++) full_round();
+#pragma unroll 1
+  for (int r = 0; r < 56; r++) {
+    const Fr x = s + dc.p2_rc[k];                        // lane 0
+    const Fr x0 = lane_get(x, 0);
+    const Fr R1 = lane_sel(lane == 0, x0, lane_sel(lane < 4, s, x0)) * lane_sel(lane == 0, x0, mu);
+    // R1: lane 0 x^2 | lanes 1..3 mu_i * s_i | lane 4 mu_0 * x
+    const Fr x2 = lane_get(R1, 0);
+    const Fr R2 = x2 * lane_sel(lane == 0, x0, x2);      // lane 0 x^3 | lane 4 x^4
+    const Fr x4 = lane_get(R2, 4);
+    const Fr R3 = x4 * lane_sel(lane == 0, x0, R1);      // lane 0 x^5 | lane 4 mu_0 * x^5
+    if (lane == 0) emit4(W, out, P, p, R1, R2, x4, R3);
+    out += 4;
+    k += 1;
+    const Fr val = lane_sel(lane == 0, R3, s);
+    Fr tot = val + lane_get(val, lane ^ 1);
+    tot = tot + lane_get(tot, lane ^ 2);
+    const Fr m0 = lane_get(R3, 4);
+    s = lane_sel(lane == 0, m0, R1) + tot;
+  }
+#pragma unroll 1
+  for (int r = 0; r < 4; r++) full_round();
+}
+
+// Poseidon (t = 3, 5): lanes 0..T-1 hold the state; lanes 8+i the x^4 halves (full rounds) or M[i][0] * x (partial rounds);
+// lanes 16 + i*T + j the MDS products M[i][j] * s_j.  In a partial round the products with j >= 1 do not wait for the S-box.
+template <int T>
+__device__ __noinline__ void coop_poseidon(const DevCircuit& dc, const Fr* __restrict__ rc, const Fr* __restrict__ mds, int rp,
+                                           Fr* __restrict__ W, uint32_t h0, uint32_t out, uint32_t P, uint32_t p, uint32_t lane) {
+  const uint32_t li = lane < T ? lane : 0;                       // state index of this lane (clamped)
+  const bool is_y = lane >= 8 && lane < 8 + T;
+  const uint32_t yi = is_y ? lane - 8 : 0;
+  const bool is_q = lane >= 16 && lane < 16 + T * T;
+  const uint32_t q = is_q ? lane - 16 : 0, qj = q % T;
+  const Fr mq = mds[q];                                          // M[qi][qj]
+  const Fr my = mds[yi * T];                                     // M[yi][0]
+  Fr s = Fr::zero();
+  if (lane < T) s = dev_row_dot(dc.H, dc.coeffs, h0 + lane, 0, W, P, p);
+#pragma unroll 1
+  for (int r = 0; r < 8 + rp; r++) {
+    s = s + rc[r * T + li];
+    const bool full = r < 4 || r >= 4 + rp;
+    if (full) {
+      const Fr x2 = s * s;
+      const Fr t = lane_get(x2, is_y ? yi : li);
+      const Fr R = t * lane_sel(lane < 8, s, t);                 // lanes < T: x^3 ; lanes 8+i: x^4
+      const Fr x4 = lane_get(R, li + 8);
+      const Fr x5 = x4 * s;
+      if (lane < T) emit4(W, out + 4 * lane, P, p, x2, R, x4, x5);
+      out += 4 * T;
+      const Fr prod = mq * lane_get(x5, qj);
+      Fr acc = lane_get(prod, 16 + li * T);
+      SPP_UNROLL for (int j = 1; j < T; j++) acc = acc + lane_get(prod, 16 + li * T + j);
+      s = acc;
+    } else {
+      const Fr x0 = lane_get(s, 0);
+      const Fr sj = lane_get(s, qj);
+      // lane 0: x * x | lanes 8+i: M[i][0] * x | lanes 16+i*T+j: M[i][j] * s_j
+      const Fr R1 = lane_sel(lane == 0, x0, lane_sel(is_y, my, mq)) * lane_sel(lane == 0 || is_y, x0, sj);
+      const Fr x2 = lane_get(R1, 0);
+      const Fr R2 = x2 * lane_sel(lane == 0, x0, x2);            // lane 0: x^3 ; lane 1: x^4
+      const Fr x4 = lane_get(R2, 1);
+      const Fr R3 = x4 * lane_sel(lane == 0, x0, R1);            // lane 0: x^5 ; lanes 8+i: M[i][0] * x^5
+      if (lane == 0) emit4(W, out, P, p, R1, R2, x4, R3);
+      out += 4;
+      Fr acc = lane_get(R3, 8 + li);
+      SPP_UNROLL for (int j = 1; j < T; j++) acc = acc + lane_get(R1, 16 + li * T + j);
+      s = acc;
+    }
+  }
+}
+
+__device__ __forceinline__ void solve_c_row(const DevCircuit& dc, Fr* __restrict__ W, uint32_t k, uint32_t P, uint32_t p) {
+  const Fr b = dev_row_dot(dc.B, dc.coeffs, k, 0, W, P, p);
+  const Fr a = (dc.row_flags[k] & 2) ? b : dev_row_dot(dc.A, dc.coeffs, k, 0, W, P, p);
+  const Fr rest = dev_row_dot(dc.C, dc.coeffs, k, 1, W, P, p);
+  const uint32_t out = dc.C.wire[dc.C.rowptr[k + 1] - 1];
+  W[(size_t)out * P + p] = a * b - rest;
+}
+
+__global__ void __launch_bounds__(64) k_solve_coop(DevCircuit dc, DevCoop co, Fr* __restrict__ W, Fr* __restrict__ scratch, uint32_t item,
+                                                   uint32_t item_end, uint32_t P) {
+  const uint32_t p = blockIdx.x, lane = threadIdx.x;
+  const uint32_t* __restrict__ pr = dc.program;
+  for (; item < item_end; item++) {
+    const uint32_t kind = co.items[3 * item], a = co.items[3 * item + 1], b = co.items[3 * item + 2];
+    switch (kind) {
+      case COOP_SEQ:
+      case COOP_PAR: {
+        // SEQ: one range, lane 0.  PAR: ranges par[2i], par[2i+1] for i in [a, b), one per lane
+        const uint32_t n = kind == COOP_SEQ ? 1 : b - a;
+        for (uint32_t i = lane; i < n; i += 64) {
+          const uint32_t pa = kind == COOP_SEQ ? a : co.par[2 * (a + i)], pb = kind == COOP_SEQ ? b : co.par[2 * (a + i) + 1];
+          solve_range(dc, W, scratch, pa, pb, P, p);
+        }
+        break;
+      }
+      case COOP_LEVELS:
+        for (uint32_t lv = a; lv < b; lv++) {
+          const uint32_t r0 = co.lvl_ptr[lv], r1 = co.lvl_ptr[lv + 1];
+          for (uint32_t r = r0 + lane; r < r1; r += 64) solve_c_row(dc, W, co.lvl_rows[r], P, p);
+          __syncthreads();
+        }
+        break;
+      case COOP_POSEIDON: {
+        const uint32_t t = pr[a + 1], h0 = pr[a + 2], out0 = pr[a + 3];
+        if (t == 3) coop_poseidon<3>(dc, dc.pos3_rc, dc.pos3_mds, 57, W, h0, out0, P, p, lane);
+        else coop_poseidon<5>(dc, dc.pos5_rc, dc.pos5_mds, 60, W, h0, out0, P, p, lane);
+        break;
+      }
+      case COOP_POSEIDON2:
+        coop_poseidon2(dc, W, pr[a + 1], pr[a + 2], P, p, lane);
+        break;
+      default:
+        return;
+    }
+    __syncthreads();   // the next item reads wires other lanes have just written
+  }
+}
+void launch_solve_coop(hipStream_t st, DevCircuit dc, DevCoop co, Fr* W, Fr* scratch, uint32_t item_begin, uint32_t item_end, uint32_t P) {
+  if (item_begin >= item_end || P == 0) return;
+  hipLaunchKernelGGL(k_solve_coop, dim3(P), dim3(64), 0, st, dc, co, W, scratch, item_begin, item_end, P);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -436,14 +626,15 @@ __device__ __forceinline__ Fr wide_finish(const uint32_t (&acc)[10]) {
   if ((acc[8] | acc[9]) == 0) return lo;
   return lo + Fr::from_u64((uint64_t)acc[8] | ((uint64_t)acc[9] << 32));
 }
+// terms first, first + step, ... of row k (first = 0, step = 1: the whole row)
 __device__ __forceinline__ Fr dev_row_dot_wide(const DevSparse& m, const Fr* __restrict__ coeffs, uint32_t k, const Fr* __restrict__ W,
-                                                uint32_t P, uint32_t p) {
+                                                uint32_t P, uint32_t p, uint32_t first = 0, uint32_t step = 1) {
   Fr acc = Fr::zero();
   uint32_t pos[10], neg[10];
   SPP_UNROLL for (int i = 0; i < 10; i++) pos[i] = neg[i] = 0;
   bool any = false;
-  const uint32_t b = m.rowptr[k], e = m.rowptr[k + 1];
-  for (uint32_t t = b; t < e; t++) {
+  const uint32_t b = m.rowptr[k] + first, e = m.rowptr[k + 1];
+  for (uint32_t t = b; t < e; t += step) {
     const uint32_t ci = m.coeff[t], li = m.lit[t];
     const Fr w = W[(size_t)m.wire[t] * P + p];
     if (ci & COEFF_ONE) acc = acc + w;
@@ -488,7 +679,48 @@ __global__ void __launch_bounds__(256) k_spmv_check(DevCircuit dc, const Fr* __r
   }
   if (bad) atomicOr(&status[p], 1u);
 }
+// small batches: SPMV_G lanes -> (constraint k, proof p), each lane takes every SPMV_G-th term of the three rows and the partial
+// sums meet through wave shuffles.  The run kernel above saves the repeated B evaluations of a batch, but a run of thousands of
+// constraints, or one row of 6 720 terms (the lookup sum of the audit circuit), is one lane's serial work there: 4.6 ms for a
+// single audit proof.
+static constexpr uint32_t SPMV_G = 16;
+__device__ __forceinline__ Fr group_sum(Fr v) {
+  SPP_UNROLL for (uint32_t off = SPMV_G / 2; off >= 1; off >>= 1) {
+    Fr o;
+    SPP_UNROLL for (int i = 0; i < 8; i++) o.l[i] = __shfl_xor(v.l[i], off);
+    v = v + o;
+  }
+  return v;
+}
+__global__ void __launch_bounds__(256) k_spmv_check_rows(DevCircuit dc, const Fr* __restrict__ W, Fr* __restrict__ abc, uint32_t n, uint32_t P,
+                                                         uint32_t* __restrict__ status) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t total = (uint64_t)n * P;
+  const uint64_t e = g / SPMV_G;           // element (k, p); the grid is padded to whole groups, every lane reaches the shuffles
+  const uint32_t sub = (uint32_t)(g % SPMV_G);
+  const bool live = e < total;
+  const uint32_t p = live ? (uint32_t)(e % P) : 0, k = live ? (uint32_t)(e / P) : dc.n_constraints;
+  Fr a = Fr::zero(), b = Fr::zero(), c = Fr::zero();
+  if (k < dc.n_constraints) {
+    a = dev_row_dot_wide(dc.A, dc.coeffs, k, W, P, p, sub, SPMV_G);
+    b = dev_row_dot_wide(dc.B, dc.coeffs, k, W, P, p, sub, SPMV_G);
+    c = dev_row_dot_wide(dc.C, dc.coeffs, k, W, P, p, sub, SPMV_G);
+  }
+  a = group_sum(a);
+  b = group_sum(b);
+  c = group_sum(c);
+  if (!live || sub != 0) return;
+  if (a * b != c) atomicOr(&status[p], 1u);
+  abc[e] = a;
+  abc[total + e] = b;
+  abc[2 * total + e] = c;
+}
 void launch_spmv_check(hipStream_t st, DevCircuit dc, const Fr* W, Fr* abc, uint32_t n, uint32_t P, uint32_t* status) {
+  if ((uint64_t)dc.n_runs * P < 65536) {
+    const uint64_t lanes = (uint64_t)n * P * SPMV_G;
+    hipLaunchKernelGGL(k_spmv_check_rows, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, st, dc, W, abc, n, P, status);
+    return;
+  }
   const uint64_t lanes = (uint64_t)(dc.n_runs + (n - dc.n_constraints)) * P;
   hipLaunchKernelGGL(k_spmv_check, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, st, dc, W, abc, n, P, status);
 }

@@ -50,7 +50,11 @@ struct PendingTable {
 struct SolveStep {
   enum Kind { SEQ, BATCH_DIV, COUNT8, COMMIT } kind;
   uint32_t a = 0, b = 0, c = 0;   // SEQ: [pc_begin, pc_end) ; BATCH_DIV: k0, n ; COUNT8: h0, n, out0
+  uint32_t item0 = 0, item1 = 0;  // SEQ: the same stretch as items of the cooperative solver (small batches)
 };
+// batches up to this size are solved by one wave per proof (k_solve_coop); above it the wave-per-64-proofs solver has the
+// better throughput (a cooperative wave runs ~1/3 of the dependent instructions, but 64 times as many waves)
+static constexpr uint32_t COOP_MAX_BATCH = 1024;
 struct spp_circuit {
   spp_ctx* ctx = nullptr;
   std::vector<SolveStep> schedule;
@@ -58,6 +62,8 @@ struct spp_circuit {
   DevCircuit dc{};
   uint32_t c_bits = 10, n = 0, logn = 0;
   uint32_t max_batch_div = SOLVE_SCRATCH_MIN_ROWS;
+  DevCoop coop{};
+  bool no_coop = false;           // SPP_NO_COOP=1 (diagnostic): always the one-lane-per-proof solver
   uint32_t row_r = 0, row_s = 0, row_rs = 0, n_rows = 0;
   uint64_t table_bytes = 0;
   MsmSet<Fq> A, B1, K, Z, CB, CS;
@@ -80,6 +86,120 @@ static int own_upload(spp_circuit* c, T** dst, const std::vector<T>& src) {
   c->owned.push_back((void*)*dst);
   return 0;
 }
+// Item list of the cooperative solver (kernels_solve.hip, k_solve_coop) for every sequential stretch of the schedule.
+// Nothing here changes what is computed: permutations become their lane-parallel form, runs of SOLVE_C rows are ordered
+// by dependency level (level of a row = 1 + the highest level among the rows of the run that write one of its inputs),
+// runs of independent BITS / LIMBS8 / INV_H instructions go one per lane, the rest stays on lane 0.
+static int coop_plan(spp_circuit* c) {
+  const Circuit& circ = c->circ;
+  const auto& pr = circ.program;
+  std::vector<uint32_t> items, par, lvl_ptr{0}, lvl_rows;
+  std::vector<uint32_t> level_of(circ.n_wires + 3, 0), stamp(circ.n_wires + 3, 0);
+  uint32_t epoch = 0;
+  auto op_len = [&](size_t pc) -> uint32_t {
+    switch (pr[pc]) {
+      case OP_SOLVE_C: case OP_SOLVE_A: return 2;
+      case OP_BATCH_DIV: case OP_POSEIDON2: case OP_INV_H: return 3;
+      case OP_COUNT8: case OP_BITS: case OP_LIMBS8: case OP_POSEIDON: return 4;
+      case OP_COMMIT: return 1;
+      case OP_GRUMPKIN: return 5 + pr[pc + 4];
+      default: return 0;
+    }
+  };
+  auto is_par_op = [&](uint32_t op) { return op == OP_BITS || op == OP_LIMBS8 || op == OP_INV_H; };
+  for (SolveStep& st : c->schedule) {
+    if (st.kind != SolveStep::SEQ) continue;
+    st.item0 = (uint32_t)(items.size() / 3);
+    size_t pc = st.a, seq0 = st.a;
+    auto push = [&](uint32_t kind, uint32_t a, uint32_t b) { items.push_back(kind); items.push_back(a); items.push_back(b); };
+    auto flush = [&](size_t end) {
+      if (end > seq0) push(COOP_SEQ, (uint32_t)seq0, (uint32_t)end);
+    };
+    while (pc < st.b) {
+      const uint32_t op = pr[pc];
+      if (op == OP_POSEIDON || op == OP_POSEIDON2) {
+        flush(pc);
+        push(op == OP_POSEIDON ? COOP_POSEIDON : COOP_POSEIDON2, (uint32_t)pc, 0);
+        pc += op_len(pc);
+        seq0 = pc;
+      } else if (op == OP_SOLVE_C) {
+        size_t e = pc;
+        while (e < st.b && pr[e] == OP_SOLVE_C) e += 2;
+        const size_t nrows = (e - pc) / 2;
+        if (nrows < 8) { pc = e; continue; }
+        flush(pc);
+        epoch++;
+        std::vector<std::pair<uint32_t, uint32_t>> rows;   // (level, constraint)
+        uint32_t max_level = 0;
+        for (size_t q = pc; q < e; q += 2) {
+          const uint32_t k = pr[q + 1];
+          uint32_t lv = 0;
+          auto scan = [&](const Sparse& m, uint32_t skip_last) {
+            for (uint32_t t = m.rowptr[k]; t + skip_last < m.rowptr[k + 1]; t++) {
+              const uint32_t w = m.terms[t].wire;
+              if (stamp[w] == epoch) lv = std::max(lv, level_of[w]);
+            }
+          };
+          scan(circ.A, 0); scan(circ.B, 0); scan(circ.C, 1);
+          const uint32_t out = circ.C.terms[circ.C.rowptr[k + 1] - 1].wire;
+          stamp[out] = epoch;
+          level_of[out] = lv + 1;
+          rows.push_back({lv, k});
+          max_level = std::max(max_level, lv);
+        }
+        std::stable_sort(rows.begin(), rows.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+        const uint32_t l0 = (uint32_t)lvl_ptr.size() - 1;
+        size_t i = 0;
+        for (uint32_t lv = 0; lv <= max_level; lv++) {
+          while (i < rows.size() && rows[i].first == lv) lvl_rows.push_back(rows[i++].second);
+          lvl_ptr.push_back((uint32_t)lvl_rows.size());
+        }
+        push(COOP_LEVELS, l0, l0 + max_level + 1);
+        pc = e;
+        seq0 = pc;
+      } else if (is_par_op(op)) {
+        // maximal run of lane-independent instructions: none may read a wire an earlier one of the run writes
+        size_t e = pc;
+        epoch++;
+        std::vector<uint32_t> group;
+        while (e < st.b && is_par_op(pr[e])) {
+          const uint32_t h = pr[e + 1];
+          bool dep = false;
+          for (uint32_t t = circ.H.rowptr[h]; t < circ.H.rowptr[h + 1]; t++) dep = dep || stamp[circ.H.terms[t].wire] == epoch;
+          if (dep) break;
+          if (pr[e] == OP_INV_H) stamp[pr[e + 2]] = epoch;
+          else for (uint32_t i = 0; i < pr[e + 2]; i++) stamp[pr[e + 3] + i] = epoch;
+          group.push_back((uint32_t)e);
+          e += op_len(e);
+        }
+        if (group.size() < 4) { pc = group.empty() ? pc + op_len(pc) : e; continue; }
+        flush(pc);
+        const uint32_t g0 = (uint32_t)(par.size() / 2);
+        for (uint32_t q : group) { par.push_back(q); par.push_back(q + op_len(q)); }
+        push(COOP_PAR, g0, g0 + (uint32_t)group.size());
+        pc = e;
+        seq0 = pc;
+      } else {
+        const uint32_t n = op_len(pc);
+        if (n == 0) return fail(SPP_ERR_FORMAT, "bad opcode %u in solver program", op);
+        pc += n;
+      }
+    }
+    flush(st.b);
+    st.item1 = (uint32_t)(items.size() / 3);
+  }
+  if (items.empty()) items.assign(3, 0);
+  if (par.empty()) par.assign(2, 0);
+  if (lvl_rows.empty()) lvl_rows.push_back(0);
+  uint32_t *d_items, *d_par, *d_lp, *d_lr;
+  int e;
+  if ((e = own_upload(c, &d_items, items)) || (e = own_upload(c, &d_par, par)) || (e = own_upload(c, &d_lp, lvl_ptr)) ||
+      (e = own_upload(c, &d_lr, lvl_rows)))
+    return e;
+  c->coop.items = d_items; c->coop.par = d_par; c->coop.lvl_ptr = d_lp; c->coop.lvl_rows = d_lr;
+  return 0;
+}
+
 static int upload_sparse(spp_circuit* c, const Circuit& circ, const Sparse& m, DevSparse* out) {
   std::vector<uint32_t> wire(m.terms.size()), coeff(m.terms.size()), lit(m.terms.size(), 0);
   Fr one = Fr::one(), mone = Fr::one().neg();
@@ -506,7 +626,17 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
     auto flush = [&](size_t end) {
       if (end > seg) c->schedule.push_back({SolveStep::SEQ, (uint32_t)seg, (uint32_t)end, 0});
     };
+    // SPP_SOLVE_TRACE=1 (diagnostic): one launch per instruction class run, so a kernel trace of a proof shows where the
+    // sequential solver spends its time
+    const bool trace_ops = getenv("SPP_SOLVE_TRACE") != nullptr;
+    c->no_coop = getenv("SPP_NO_COOP") != nullptr || trace_ops;
+    uint32_t prev_op = OP_END;
     while (pc < pr.size() && pr[pc] != OP_END) {
+      if (trace_ops && pr[pc] != prev_op) {
+        flush(pc);
+        seg = std::max(seg, pc);
+      }
+      prev_op = pr[pc];
       switch (pr[pc]) {
         case OP_SOLVE_C: case OP_SOLVE_A: pc += 2; break;
         case OP_BATCH_DIV:
@@ -538,6 +668,8 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
     }
     flush(pc);
   }
+
+  if (int e = coop_plan(c)) return e;
 
   // ---- NTT tables ----
   {
@@ -699,6 +831,7 @@ static int ws_set(Workspace& w, const MsmSet<F>* s, MsmBuf<F>* b, size_t P) {
   size_t max_s = std::max<size_t>((s->N + 3) / 4, 1);
   b->partial_cap = std::min<size_t>((size_t)256 * 4 * 4 * 64 + P, max_s * P);
   b->partial_cap = std::max<size_t>(b->partial_cap, (size_t)msm_slices(s->N, (uint32_t)P) * P);
+  b->partial_cap = std::max<size_t>(b->partial_cap, 65536 + P);   // small batches: up to 64K (base, window chunk) lanes
   int e;
   if ((e = ws_alloc(w, &b->partial, b->partial_cap))) return e;
   return ws_alloc(w, &b->out, P);
@@ -728,13 +861,14 @@ static void run_msm(spp_circuit* c, Workspace& w, const MsmSet<F>& s, MsmBuf<F>&
                     std::pair<hipEvent_t, hipEvent_t>* ev_override = nullptr) {
   hipStream_t st = st_override ? st_override : w.st;
   const Fr* scal = s.from_h ? w.abc : w.W;
-  uint32_t S = msm_slices(s.N, P);
+  const uint32_t Q = msm_window_chunks(s.N, P, s.c);   // > 1 for small batches: the windows of a base are shared by Q lanes
+  uint32_t S = msm_slices_split(s.N, P, Q);
   while (S > 1 && (size_t)S * P > b.partial_cap) S--;  // never exceed the allocated partial buffer
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
   if (timed && w.msm_ev_used < w.msm_ev.size()) ev = &w.msm_ev[w.msm_ev_used++];
   if (ev_override) ev = ev_override;
   // the event pair receives the dispatch's own start/stop timestamps (what rocprofv3 reports as the kernel's duration)
-  launch_msm_accumulate<F>(st, s.table, s.rows, scal, b.partial, s.N, P, s.c, S, ev ? ev->first : nullptr, ev ? ev->second : nullptr);
+  launch_msm_accumulate<F>(st, s.table, s.rows, scal, b.partial, s.N, P, s.c, S, ev ? ev->first : nullptr, ev ? ev->second : nullptr, Q);
   launch_msm_reduce<F>(st, b.partial, b.out, P, s.N ? S : 0);
 }
 
@@ -751,7 +885,10 @@ static int prove_on_device(spp_circuit* c, Workspace& w, uint32_t P, const uint8
   launch_load_inputs(st, d_inputs, d_rs, w.W, circ.n_inputs(), circ.n_wires, P);
   for (const SolveStep& s : c->schedule) {
     switch (s.kind) {
-      case SolveStep::SEQ: launch_solve(st, c->dc, w.W, w.scratch, s.a, s.b, P); break;
+      case SolveStep::SEQ:
+        if (P <= COOP_MAX_BATCH && !c->no_coop) launch_solve_coop(st, c->dc, c->coop, w.W, w.scratch, s.item0, s.item1, P);
+        else launch_solve(st, c->dc, w.W, w.scratch, s.a, s.b, P);
+        break;
       case SolveStep::BATCH_DIV: launch_batch_div(st, c->dc, w.W, w.scratch, s.a, s.b, P); break;
       case SolveStep::COUNT8: launch_count8(st, c->dc, w.W, w.counters, s.a, s.b, s.c, P); break;
       case SolveStep::COMMIT:
