@@ -149,6 +149,16 @@ void launch_msm_accumulate(hipStream_t st, const Affine<F>* table, const uint32_
 // out[p] = sum_s partial[s][p]   (S = 0: out[p] = infinity); folds in place: `partial` is scratch afterwards
 template <class F>
 void launch_msm_reduce(hipStream_t st, XYZZ<F>* partial, XYZZ<F>* out, uint32_t P, uint32_t S);
+// several sets folded by the same launches (one launch per level for all of them)
+static constexpr uint32_t MSM_FOLD_SETS = 6;
+template <class F>
+struct MsmFoldSets {
+  XYZZ<F>* partial[MSM_FOLD_SETS];
+  XYZZ<F>* out[MSM_FOLD_SETS];
+  uint32_t cur[MSM_FOLD_SETS], half[MSM_FOLD_SETS];   // filled per level by launch_msm_reduce_multi
+};
+template <class F>
+void launch_msm_reduce_multi(hipStream_t st, MsmFoldSets<F> fs, uint32_t nsets, const uint32_t* S, uint32_t P);
 uint32_t msm_windows(uint32_t c);
 uint32_t msm_slices(uint32_t N, uint32_t P);
 uint32_t msm_window_chunks(uint32_t N, uint32_t P, uint32_t c);   // Q: lanes per base for small batches (1 = none)

@@ -557,21 +557,23 @@ void launch_solve_coop(hipStream_t st, DevCircuit dc, DevCoop co, Fr* W, Fr* scr
 // ---------------------------------------------------------------------------------------------------
 // wide OP_BATCH_DIV: lane -> (chunk of DIV_CHUNK consecutive constraints, proof); one inversion per chunk
 // ---------------------------------------------------------------------------------------------------
-static constexpr uint32_t DIV_CHUNK = 32;
+// (chunk = 32 for batches: one inversion per 32 divisions; 4 for small batches, where the lanes are free and the chain of
+// prefix products is what a proof waits for)
 __global__ void __launch_bounds__(64) k_batch_div(DevCircuit dc, Fr* __restrict__ W, Fr* __restrict__ scratch, uint32_t k0, uint32_t n,
-                                                  uint32_t P) {
+                                                  uint32_t P, uint32_t chunk_len) {
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t nchunks = (n + DIV_CHUNK - 1) / DIV_CHUNK;
+  const uint32_t nchunks = (n + chunk_len - 1) / chunk_len;
   if (g >= (uint64_t)nchunks * P) return;
   const uint32_t p = (uint32_t)(g % P), chunk = (uint32_t)(g / P);
-  const uint32_t i0 = chunk * DIV_CHUNK;
-  const uint32_t cnt = n - i0 < DIV_CHUNK ? n - i0 : DIV_CHUNK;
+  const uint32_t i0 = chunk * chunk_len;
+  const uint32_t cnt = n - i0 < chunk_len ? n - i0 : chunk_len;
   dev_div_range(dc, W, scratch + (size_t)i0 * P, k0 + i0, cnt, P, p);
 }
 void launch_batch_div(hipStream_t st, DevCircuit dc, Fr* W, Fr* scratch, uint32_t k0, uint32_t n, uint32_t P) {
   if (n == 0) return;
-  uint64_t lanes = (uint64_t)((n + DIV_CHUNK - 1) / DIV_CHUNK) * P;
-  hipLaunchKernelGGL(k_batch_div, dim3((uint32_t)((lanes + 63) / 64)), dim3(64), 0, st, dc, W, scratch, k0, n, P);
+  const uint32_t chunk_len = P >= 256 ? 32 : 4;
+  uint64_t lanes = (uint64_t)((n + chunk_len - 1) / chunk_len) * P;
+  hipLaunchKernelGGL(k_batch_div, dim3((uint32_t)((lanes + 63) / 64)), dim3(64), 0, st, dc, W, scratch, k0, n, P, chunk_len);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -64,6 +64,7 @@ struct spp_circuit {
   uint32_t max_batch_div = SOLVE_SCRATCH_MIN_ROWS;
   DevCoop coop{};
   bool no_coop = false;           // SPP_NO_COOP=1 (diagnostic): always the one-lane-per-proof solver
+  bool trace_items = false;       // SPP_COOP_TRACE=1 (diagnostic): one launch per item of the cooperative solver
   uint32_t row_r = 0, row_s = 0, row_rs = 0, n_rows = 0;
   uint64_t table_bytes = 0;
   MsmSet<Fq> A, B1, K, Z, CB, CS;
@@ -630,6 +631,7 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
     // sequential solver spends its time
     const bool trace_ops = getenv("SPP_SOLVE_TRACE") != nullptr;
     c->no_coop = getenv("SPP_NO_COOP") != nullptr || trace_ops;
+    c->trace_items = getenv("SPP_COOP_TRACE") != nullptr;
     uint32_t prev_op = OP_END;
     while (pc < pr.size() && pr[pc] != OP_END) {
       if (trace_ops && pr[pc] != prev_op) {
@@ -858,7 +860,7 @@ static int ensure_workspace(spp_circuit* c, Workspace& w, size_t P) {
 
 template <class F>
 static void run_msm(spp_circuit* c, Workspace& w, const MsmSet<F>& s, MsmBuf<F>& b, uint32_t P, bool timed, hipStream_t st_override = nullptr,
-                    std::pair<hipEvent_t, hipEvent_t>* ev_override = nullptr) {
+                    std::pair<hipEvent_t, hipEvent_t>* ev_override = nullptr, uint32_t* S_out = nullptr) {
   hipStream_t st = st_override ? st_override : w.st;
   const Fr* scal = s.from_h ? w.abc : w.W;
   const uint32_t Q = msm_window_chunks(s.N, P, s.c);   // > 1 for small batches: the windows of a base are shared by Q lanes
@@ -869,7 +871,8 @@ static void run_msm(spp_circuit* c, Workspace& w, const MsmSet<F>& s, MsmBuf<F>&
   if (ev_override) ev = ev_override;
   // the event pair receives the dispatch's own start/stop timestamps (what rocprofv3 reports as the kernel's duration)
   launch_msm_accumulate<F>(st, s.table, s.rows, scal, b.partial, s.N, P, s.c, S, ev ? ev->first : nullptr, ev ? ev->second : nullptr, Q);
-  launch_msm_reduce<F>(st, b.partial, b.out, P, s.N ? S : 0);
+  if (S_out) *S_out = s.N ? S : 0;   // the caller folds several sets together
+  else launch_msm_reduce<F>(st, b.partial, b.out, P, s.N ? S : 0);
 }
 
 static int prove_on_device(spp_circuit* c, Workspace& w, uint32_t P, const uint8_t* d_inputs, const uint8_t* d_rs, uint8_t* d_proofs,
@@ -886,7 +889,9 @@ static int prove_on_device(spp_circuit* c, Workspace& w, uint32_t P, const uint8
   for (const SolveStep& s : c->schedule) {
     switch (s.kind) {
       case SolveStep::SEQ:
-        if (P <= COOP_MAX_BATCH && !c->no_coop) launch_solve_coop(st, c->dc, c->coop, w.W, w.scratch, s.item0, s.item1, P);
+        if (P <= COOP_MAX_BATCH && !c->no_coop && c->trace_items)
+          for (uint32_t it = s.item0; it < s.item1; it++) launch_solve_coop(st, c->dc, c->coop, w.W, w.scratch, it, it + 1, P);
+        else if (P <= COOP_MAX_BATCH && !c->no_coop) launch_solve_coop(st, c->dc, c->coop, w.W, w.scratch, s.item0, s.item1, P);
         else launch_solve(st, c->dc, w.W, w.scratch, s.a, s.b, P);
         break;
       case SolveStep::BATCH_DIV: launch_batch_div(st, c->dc, w.W, w.scratch, s.a, s.b, P); break;
@@ -915,11 +920,18 @@ static int prove_on_device(spp_circuit* c, Workspace& w, uint32_t P, const uint8
   launch_ntt(st, w.abc, c->logn, P, c->tw_inv, true, 1, bs, c->coset_inv_br);
   hipEventRecord(w.ev[3], st);
   // 4. MSMs
-  run_msm(c, w, c->A, w.A, P, true);
-  run_msm(c, w, c->B1, w.B1, P, true);
-  run_msm(c, w, c->K, w.K, P, true);
-  run_msm(c, w, c->Z, w.Z, P, true);
-  run_msm(c, w, c->CS, w.CS, P, true);
+  {
+    MsmFoldSets<Fq> fs{};
+    uint32_t S[5];
+    const MsmSet<Fq>* sets[5] = {&c->A, &c->B1, &c->K, &c->Z, &c->CS};
+    MsmBuf<Fq>* bufs[5] = {&w.A, &w.B1, &w.K, &w.Z, &w.CS};
+    for (int i = 0; i < 5; i++) {
+      run_msm(c, w, *sets[i], *bufs[i], P, true, nullptr, nullptr, &S[i]);
+      fs.partial[i] = bufs[i]->partial;
+      fs.out[i] = bufs[i]->out;
+    }
+    launch_msm_reduce_multi<Fq>(st, fs, 5, S, P);   // the five partial-sum arrays are folded level by level in shared launches
+  }
   hipEventRecord(w.ev[4], st);
   hipStreamWaitEvent(st, w.ev_b2, 0);   // join the G2 MSM
   hipEventRecord(w.ev[5], st);

@@ -32,6 +32,15 @@ template <class F> static void field_ops(const std::string& op, std::istringstre
   else if (op == "sub") { F a = rd<F>(is), b = rd<F>(is); std::cout << hx(a - b) << "\n"; }
   else if (op == "neg") { F a = rd<F>(is); std::cout << hx(a.neg()) << "\n"; }
   else if (op == "inv") { F a = rd<F>(is); std::cout << hx(a.inv()) << "\n"; }
+  else if (op == "invf") { F a = rd<F>(is); std::cout << hx(a.inv_fermat()) << "\n"; }
+  else if (op == "invnc") {   // the non-canonical word (value + p, still < 2p) of the same element
+    F a = rd<F>(is), m;
+    for (int i = 0; i < 8; i++) m.l[i] = F::zero().l[i];
+    uint32_t c = 0;
+    F w = a;
+    for (int i = 0; i < 8; i++) { uint64_t t = (uint64_t)a.l[i] + F::modulus_word(i) + c; w.l[i] = (uint32_t)t; c = (uint32_t)(t >> 32); }
+    if (!F::geq_mod(a.l) ) std::cout << hx(w.inv()) << "\n"; else std::cout << hx(a.inv()) << "\n";
+  }
   else if (op == "u256") { std::string h; is >> h; uint32_t c[8]; parse_hex(h, c); std::cout << hx(F::from_u256(c)) << "\n"; }
   else if (op == "small") { F a = rd<F>(is); unsigned k; is >> k; std::cout << hx(a.mul_small(k)) << "\n"; }
 }

@@ -52,9 +52,16 @@ def test_host_arithmetic_header_matches_oracle(tmp_path):
             lines.append("%s add %s %s" % (name, h(a), h(b))); exp.append(h((a + b) % m))
             lines.append("%s sub %s %s" % (name, h(a), h(b))); exp.append(h((a - b) % m))
             lines.append("%s neg %s" % (name, h(a))); exp.append(h((-a) % m))
+        # inverses: the binary extended Euclid of Fp::inv() against Python, against a^(p-2), on the non-canonical word of the
+        # same element, and on the values that drive its shift counts to the extremes (1, 2^k, p-1, (p+-1)/2, tiny, 0)
+        inv_cases = [rng.randrange(1, m) for _ in range(120)] + [1, 2, 3, m - 1, m - 2, (m - 1) // 2, (m + 1) // 2, 1 << 128, 1 << 253,
+                                                                  (1 << 253) + 1, 0xffffffff, 1 << 32, (1 << 64) - 1, m >> 1, 5]
+        for a in inv_cases:
+            for op in ("inv", "invf", "invnc"):
+                lines.append("%s %s %s" % (name, op, h(a))); exp.append(h(pow(a, -1, m)))
+        lines.append("%s inv %s" % (name, h(0))); exp.append(h(0))
         for _ in range(4):
             a = rng.randrange(1, m)
-            lines.append("%s inv %s" % (name, h(a))); exp.append(h(pow(a, -1, m)))
             u = rng.randrange(1 << 256)
             lines.append("%s u256 %s" % (name, h(u))); exp.append(h(u % m))
     for _ in range(6):
