@@ -1,6 +1,9 @@
 import json, os, sys, tempfile, time
 ROOT="/root/repo"; sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "shielded-pool-pinocchio-solana_amd"))
 import torch, spp
+# full-size blinding factors (what a real prover draws): the s*Ar / r*Bs1 part of the assembly depends on their length
+R1 = 0x1f3a9c0de4b5a697887766554433221100ffeeddccbbaa998877665544332211 % (1 << 253)
+R2 = 0x0e2d4c6b8a79685746352413021f0e0dccbbaa99887766554433221100fedcba
 from spp import workload
 dev=torch.device("cuda",0)
 tmp=tempfile.mkdtemp()
@@ -13,7 +16,7 @@ for cid,name in ((1,"withdraw"),(2,"audit")):
         t0=time.time(); h=ctx.load_circuit(sppc,pkp,win); load=time.time()-t0
         rows=workload.withdraw_rows(ctx,1) if cid==1 else workload.audit_rows(ctx,pk["a"],pk["b"],1)
         inp=torch.frombuffer(bytearray(rows),dtype=torch.uint8).to(dev)
-        rs=torch.frombuffer(bytearray((5).to_bytes(32,"big")+(6).to_bytes(32,"big")),dtype=torch.uint8).to(dev)
+        rs=torch.frombuffer(bytearray((R1).to_bytes(32,"big")+(R2).to_bytes(32,"big")),dtype=torch.uint8).to(dev)
         pr=torch.zeros(388,dtype=torch.uint8,device=dev); pw=torch.zeros(h.pw_len,dtype=torch.uint8,device=dev); st=torch.zeros(1,dtype=torch.int32,device=dev)
         lat=[]
         for _ in range(8):

@@ -107,7 +107,7 @@ void launch_load_inputs(hipStream_t st, const uint8_t* d_inputs_be, const uint8_
 static constexpr uint32_t SOLVE_SCRATCH_MIN_ROWS = 324;
 void launch_solve(hipStream_t st, DevCircuit dc, Fr* W, Fr* scratch, uint32_t pc_begin, uint32_t pc_end, uint32_t P);
 // cooperative solver for small batches (one wave per proof; kernels_solve.hip): items = (kind, a, b) triples
-enum : uint32_t { COOP_SEQ = 0, COOP_PAR = 1, COOP_LEVELS = 2, COOP_POSEIDON = 3, COOP_POSEIDON2 = 4 };
+enum : uint32_t { COOP_SEQ = 0, COOP_PAR = 1, COOP_LEVELS = 2, COOP_POSEIDON = 3, COOP_POSEIDON2 = 4, COOP_GRUMPKIN = 5 };
 struct DevCoop {
   const uint32_t* items;      // 3 words per item
   const uint32_t* par;        // COOP_PAR: (pc_begin, pc_end) pairs of independent instructions
@@ -150,7 +150,7 @@ void launch_msm_accumulate(hipStream_t st, const Affine<F>* table, const uint32_
 template <class F>
 void launch_msm_reduce(hipStream_t st, XYZZ<F>* partial, XYZZ<F>* out, uint32_t P, uint32_t S);
 // several sets folded by the same launches (one launch per level for all of them)
-static constexpr uint32_t MSM_FOLD_SETS = 6;
+static constexpr uint32_t MSM_FOLD_SETS = 8;
 template <class F>
 struct MsmFoldSets {
   XYZZ<F>* partial[MSM_FOLD_SETS];
@@ -177,11 +177,15 @@ struct AssembleArgs {
   const G1XYZZ* mA; const G1XYZZ* mB1; const G2XYZZ* mB2; const G1XYZZ* mK; const G1XYZZ* mZ; const G1XYZZ* mPok;
   const G1Affine* commit_affine;
   const Fr* W; uint32_t row_r, row_s; uint32_t n_public;
+  // small batches: s*Ar and r*Bs1 arrive as two more fixed-base sums over the scaled witness (nullptr: the lanes multiply)
+  const G1XYZZ* sAr; const G1XYZZ* rBs1;
   uint8_t* proofs;   // [P][388]
   uint8_t* pws;      // [P][12+32*(n_public-1)]
   uint32_t P;
 };
 void launch_assemble(hipStream_t st, AssembleArgs a);
+// Ws[row][p] = s_p * W[row][p], Wr[row][p] = r_p * W[row][p] for rows < n_rows (r, s = rows row_r, row_s of W)
+void launch_scale_witness(hipStream_t st, const Fr* W, Fr* Ws, Fr* Wr, uint32_t n_rows, uint32_t row_r, uint32_t row_s, uint32_t P);
 
 // ---- setup helpers ----
 // out[i] = scalars[i] * G for a generator table built with launch_build_table (N=1)

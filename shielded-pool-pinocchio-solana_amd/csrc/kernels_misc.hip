@@ -76,7 +76,8 @@ __global__ void __launch_bounds__(64) k_assemble(AssembleArgs a) {
     const Fr sc = a.W[(size_t)(role == 0 ? a.row_s : a.row_r) * a.P + p];
     sc.to_canonical(k);
   }
-  G1XYZZ part = dev_scalar_mul_g1(base, k);
+  // s*Ar / r*Bs1: handed in (small batches, two more table sums over the scaled witness) or 254 doublings by this lane
+  G1XYZZ part = a.sAr ? (live ? (role == 0 ? a.sAr[p] : a.rBs1[p]) : G1XYZZ::infinity()) : dev_scalar_mul_g1(base, k);
   sh[threadIdx.x] = part;
   __syncthreads();
   if (!live || role != 0) return;
@@ -113,6 +114,19 @@ __global__ void __launch_bounds__(64) k_assemble(AssembleArgs a) {
     fr_to_be_words(a.W[(size_t)(1 + i) * a.P + p], w);
     store_be_words(pw + 12 + 32 * i, w, 8);
   }
+}
+__global__ void __launch_bounds__(256) k_scale_witness(const Fr* __restrict__ W, Fr* __restrict__ Ws, Fr* __restrict__ Wr, uint32_t n_rows,
+                                                       uint32_t row_r, uint32_t row_s, uint32_t P) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (uint64_t)n_rows * P) return;
+  const uint32_t p = (uint32_t)(g % P);
+  const Fr w = W[g];
+  Ws[g] = w * W[(size_t)row_s * P + p];
+  Wr[g] = w * W[(size_t)row_r * P + p];
+}
+void launch_scale_witness(hipStream_t st, const Fr* W, Fr* Ws, Fr* Wr, uint32_t n_rows, uint32_t row_r, uint32_t row_s, uint32_t P) {
+  const uint64_t total = (uint64_t)n_rows * P;
+  hipLaunchKernelGGL(k_scale_witness, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, W, Ws, Wr, n_rows, row_r, row_s, P);
 }
 void launch_assemble(hipStream_t st, AssembleArgs a) {
   uint32_t lanes = 2 * a.P;

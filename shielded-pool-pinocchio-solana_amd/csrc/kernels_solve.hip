@@ -381,6 +381,7 @@ void launch_solve(hipStream_t st, DevCircuit dc, Fr* W, Fr* scratch, uint32_t pc
 //   COOP_LEVELS    a run of SOLVE_C rows in dependency levels: the rows of a level are solved by different lanes
 //   COOP_POSEIDON  one permutation: state words, the two halves of every S-box (x^3 | x^4) and the MDS products on
 //   COOP_POSEIDON2 different lanes -- three dependent multiplications per partial round instead of 13 (t = 3) / 8
+//   COOP_GRUMPKIN  the fixed-base ladder as a 64-lane prefix sum, one window per lane
 // The values written are the same field elements as the one-lane solver's (the words may be another representative < 2p).
 __device__ __forceinline__ Fr lane_get(const Fr& v, uint32_t src) {
   Fr r;
@@ -502,6 +503,44 @@ __device__ __noinline__ void coop_poseidon(const DevCircuit& dc, const Fr* __res
   }
 }
 
+// OP_GRUMPKIN on 64 lanes: lane j looks up the table point of window j, a shuffle scan (six XYZZ additions) leaves
+// acc_j = O + T_0[d_0] + ... + T_j[d_j] in lane j, every lane normalises its own point and divides for its own slope
+// (the one-lane form walks the 64 additions and two batch inversions in sequence: 1.7 ms of a proof).
+__device__ __noinline__ void coop_grumpkin(const DevCircuit& dc, Fr* __restrict__ W, const uint32_t* __restrict__ op, uint32_t P, uint32_t p,
+                                           uint32_t lane) {
+  const uint32_t bit0 = op[1], nbits = op[2], nl = op[4];
+  const uint32_t* __restrict__ lw = op + 5;
+  const Fr* __restrict__ aux = dc.aux + op[3];
+  uint32_t d = 0;
+  for (uint32_t k = 0; k < 4; k++) {
+    const uint32_t bi = 4 * lane + k;
+    if (bi < nbits && !W[(size_t)(bit0 + bi) * P + p].is_zero()) d |= 1u << k;
+  }
+  const GkAffine mine{aux[4 + (lane * 16 + d) * 2], aux[4 + (lane * 16 + d) * 2 + 1]};
+  const GkAffine O{aux[0], aux[1]}, N{aux[2], aux[3]};
+  GkXYZZ acc = GkXYZZ::from_affine(lane == 0 ? O : mine);
+  if (lane == 0) acc.madd(mine);
+#pragma unroll 1
+  for (uint32_t off = 1; off < 64; off <<= 1) {
+    const uint32_t src = lane >= off ? lane - off : lane;
+    GkXYZZ o;
+    o.X = lane_get(acc.X, src);
+    o.Y = lane_get(acc.Y, src);
+    o.ZZ = lane_get(acc.ZZ, src);
+    o.ZZZ = lane_get(acc.ZZZ, src);
+    if (lane >= off) acc.add(o);
+  }
+  const GkAffine a = acc.to_affine();
+  GkAffine prev{lane_get(a.x, lane ? lane - 1 : 0), lane_get(a.y, lane ? lane - 1 : 0)};
+  if (lane == 0) prev = O;
+  const Fr den = mine.x - prev.x;
+  if (lane < nl) W[(size_t)lw[lane] * P + p] = (mine.y - prev.y) * den.inv();   // inv(0) = 0: slope 0, as the one-lane form
+  if (lane == 63 && nl > 64) {
+    const Fr den2 = N.x - a.x;
+    W[(size_t)lw[64] * P + p] = (N.y - a.y) * den2.inv();
+  }
+}
+
 __device__ __forceinline__ void solve_c_row(const DevCircuit& dc, Fr* __restrict__ W, uint32_t k, uint32_t P, uint32_t p) {
   const Fr b = dev_row_dot(dc.B, dc.coeffs, k, 0, W, P, p);
   const Fr a = (dc.row_flags[k] & 2) ? b : dev_row_dot(dc.A, dc.coeffs, k, 0, W, P, p);
@@ -542,6 +581,9 @@ __global__ void __launch_bounds__(64) k_solve_coop(DevCircuit dc, DevCoop co, Fr
       }
       case COOP_POSEIDON2:
         coop_poseidon2(dc, W, pr[a + 1], pr[a + 2], P, p, lane);
+        break;
+      case COOP_GRUMPKIN:
+        coop_grumpkin(dc, W, pr + a, P, p, lane);
         break;
       default:
         return;

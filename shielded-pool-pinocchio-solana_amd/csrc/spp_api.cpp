@@ -34,6 +34,8 @@ struct Workspace {
   uint32_t* d_status = nullptr;
   uint32_t* counters = nullptr;   // [256][P] lookup histogram
   MsmBuf<Fq> A, B1, K, Z, CB, CS;
+  MsmBuf<Fq> sA, rB;                  // small batches: s*Ar and r*Bs1 as table sums over the scaled witness (Ws, Wr)
+  Fr *Ws = nullptr, *Wr = nullptr;
   MsmBuf<Fq2> B2;
   std::vector<void*> owned;
   hipEvent_t ev[8] = {};
@@ -55,6 +57,10 @@ struct SolveStep {
 // batches up to this size are solved by one wave per proof (k_solve_coop); above it the wave-per-64-proofs solver has the
 // better throughput (a cooperative wave runs ~1/3 of the dependent instructions, but 64 times as many waves)
 static constexpr uint32_t COOP_MAX_BATCH = 1024;
+// Up to this batch size s*Ar and r*Bs1 are two more fixed-base sums (sets A and B1 over the witness scaled by s and r) instead of
+// 254 doublings on one lane each: 3 ms of a single proof's 9.  The sums cost a third of a proof's table additions, so a batch
+// keeps the per-lane multiplication (its latency is shared by the whole batch).
+static constexpr uint32_t SCALED_BLIND_MAX_BATCH = 16;
 struct spp_circuit {
   spp_ctx* ctx = nullptr;
   std::vector<SolveStep> schedule;
@@ -118,9 +124,9 @@ static int coop_plan(spp_circuit* c) {
     };
     while (pc < st.b) {
       const uint32_t op = pr[pc];
-      if (op == OP_POSEIDON || op == OP_POSEIDON2) {
+      if (op == OP_POSEIDON || op == OP_POSEIDON2 || (op == OP_GRUMPKIN && pr[pc + 4] >= 64 && pr[pc + 4] <= 65)) {
         flush(pc);
-        push(op == OP_POSEIDON ? COOP_POSEIDON : COOP_POSEIDON2, (uint32_t)pc, 0);
+        push(op == OP_POSEIDON ? COOP_POSEIDON : op == OP_POSEIDON2 ? COOP_POSEIDON2 : COOP_GRUMPKIN, (uint32_t)pc, 0);
         pc += op_len(pc);
         seq0 = pc;
       } else if (op == OP_SOLVE_C) {
@@ -854,15 +860,21 @@ static int ensure_workspace(spp_circuit* c, Workspace& w, size_t P) {
       (e = ws_set(w, &c->K, &w.K, P)) || (e = ws_set(w, &c->Z, &w.Z, P)) || (e = ws_set(w, &c->CB, &w.CB, P)) ||
       (e = ws_set(w, &c->CS, &w.CS, P)))
     return e;
+  {
+    const size_t Ps = std::min<size_t>(P, SCALED_BLIND_MAX_BATCH);
+    if ((e = ws_set(w, &c->A, &w.sA, Ps)) || (e = ws_set(w, &c->B1, &w.rB, Ps)) || (e = ws_alloc(w, &w.Ws, (size_t)c->n_rows * Ps)) ||
+        (e = ws_alloc(w, &w.Wr, (size_t)c->n_rows * Ps)))
+      return e;
+  }
   w.cap = P;
   return 0;
 }
 
 template <class F>
 static void run_msm(spp_circuit* c, Workspace& w, const MsmSet<F>& s, MsmBuf<F>& b, uint32_t P, bool timed, hipStream_t st_override = nullptr,
-                    std::pair<hipEvent_t, hipEvent_t>* ev_override = nullptr, uint32_t* S_out = nullptr) {
+                    std::pair<hipEvent_t, hipEvent_t>* ev_override = nullptr, uint32_t* S_out = nullptr, const Fr* scal_override = nullptr) {
   hipStream_t st = st_override ? st_override : w.st;
-  const Fr* scal = s.from_h ? w.abc : w.W;
+  const Fr* scal = scal_override ? scal_override : s.from_h ? w.abc : w.W;
   const uint32_t Q = msm_window_chunks(s.N, P, s.c);   // > 1 for small batches: the windows of a base are shared by Q lanes
   uint32_t S = msm_slices_split(s.N, P, Q);
   while (S > 1 && (size_t)S * P > b.partial_cap) S--;  // never exceed the allocated partial buffer
@@ -882,6 +894,7 @@ static int prove_on_device(spp_circuit* c, Workspace& w, uint32_t P, const uint8
   const uint32_t n = c->n;
   w.msm_ev_used = 0;
   w.last_P = P;
+  const bool scaled_blind = P <= SCALED_BLIND_MAX_BATCH && !c->no_coop;
   HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(uint32_t) * P, st));
   hipEventRecord(w.ev[0], st);
   // 1. inputs, solver phase 1, commitment, challenge, solver phase 2
@@ -922,15 +935,18 @@ static int prove_on_device(spp_circuit* c, Workspace& w, uint32_t P, const uint8
   // 4. MSMs
   {
     MsmFoldSets<Fq> fs{};
-    uint32_t S[5];
-    const MsmSet<Fq>* sets[5] = {&c->A, &c->B1, &c->K, &c->Z, &c->CS};
-    MsmBuf<Fq>* bufs[5] = {&w.A, &w.B1, &w.K, &w.Z, &w.CS};
-    for (int i = 0; i < 5; i++) {
-      run_msm(c, w, *sets[i], *bufs[i], P, true, nullptr, nullptr, &S[i]);
+    uint32_t S[7];
+    const MsmSet<Fq>* sets[7] = {&c->A, &c->B1, &c->K, &c->Z, &c->CS, &c->A, &c->B1};
+    MsmBuf<Fq>* bufs[7] = {&w.A, &w.B1, &w.K, &w.Z, &w.CS, &w.sA, &w.rB};
+    const Fr* scal[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, w.Ws, w.Wr};
+    const int nsets = scaled_blind ? 7 : 5;
+    if (scaled_blind) launch_scale_witness(st, w.W, w.Ws, w.Wr, c->n_rows, c->row_r, c->row_s, P);
+    for (int i = 0; i < nsets; i++) {
+      run_msm(c, w, *sets[i], *bufs[i], P, i < 5, nullptr, nullptr, &S[i], scal[i]);
       fs.partial[i] = bufs[i]->partial;
       fs.out[i] = bufs[i]->out;
     }
-    launch_msm_reduce_multi<Fq>(st, fs, 5, S, P);   // the five partial-sum arrays are folded level by level in shared launches
+    launch_msm_reduce_multi<Fq>(st, fs, nsets, S, P);   // the partial-sum arrays are folded level by level in shared launches
   }
   hipEventRecord(w.ev[4], st);
   hipStreamWaitEvent(st, w.ev_b2, 0);   // join the G2 MSM
@@ -940,6 +956,8 @@ static int prove_on_device(spp_circuit* c, Workspace& w, uint32_t P, const uint8
   a.mA = w.A.out; a.mB1 = w.B1.out; a.mB2 = w.B2.out; a.mK = w.K.out; a.mZ = w.Z.out; a.mPok = w.CS.out;
   a.commit_affine = w.commit_affine;
   a.W = w.W; a.row_r = c->row_r; a.row_s = c->row_s; a.n_public = circ.n_public;
+  a.sAr = scaled_blind ? w.sA.out : nullptr;
+  a.rBs1 = scaled_blind ? w.rB.out : nullptr;
   a.proofs = d_proofs; a.pws = d_pws; a.P = P;
   launch_assemble(st, a);
   hipEventRecord(w.ev[6], st);
