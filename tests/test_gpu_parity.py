@@ -958,3 +958,47 @@ def test_auditor_side_reconstruct_and_decrypt(ctx, rlwe_pk, rlwe_vectors):
     _, got = witness.rlwe_decrypt(ctx, skr, c0, c1)
     for i in (0, 7, 32):
         assert got[i].tolist() == rlwe.rlwe_decrypt(skr.tolist(), c0[i].tolist(), c1[i].tolist())
+
+
+def test_small_batch_paths_agree_with_the_batch_paths(ctx, withdraw_artifacts, audit_artifacts, rlwe_pk, monkeypatch):
+    """Batches up to 1024 proofs take the one-wave-per-proof solver (lane-parallel Poseidon / Poseidon2 / Grumpkin, SOLVE_C rows
+    by dependency level), batches up to 16 also replace s*Ar and r*Bs1 by table sums over the scaled witness, small launches split
+    the windows of a base over lanes and evaluate matrix rows 16 lanes at a time.  None of that may change a byte: the same rows
+    and (full-size) blinding factors give the same proofs at batch sizes 1, 3, 17 (cooperative), through a handle loaded with
+    SPP_NO_COOP=1 (always one lane per proof, lanes multiply the blinding), and inside a batch of 1100 (past the threshold)."""
+    from spp import workload
+    import ctypes
+    rng = random.Random(2024)
+    from oracle.bn254 import R
+
+    def prove(h, rows_b, n, rs):
+        proofs = ctypes.create_string_buffer(388 * n)
+        pws = ctypes.create_string_buffer(h.pw_len * n)
+        status = (ctypes.c_int32 * n)()
+        rc = h.L.spp_prove_batch(h.h, n, rows_b, rs, ctypes.cast(proofs, ctypes.c_void_p), ctypes.cast(pws, ctypes.c_void_p),
+                                 ctypes.cast(status, ctypes.c_void_p))
+        assert rc == 0 and not any(status)
+        return [proofs.raw[388 * i:388 * (i + 1)] for i in range(n)], [pws.raw[h.pw_len * i:h.pw_len * (i + 1)] for i in range(n)]
+
+    for name, art, big in (("withdraw", withdraw_artifacts, 1100), ("audit", audit_artifacts, 1100)):
+        h = ctx.load_circuit(art["sppc"], art["pk"], 6)
+        monkeypatch.setenv("SPP_NO_COOP", "1")
+        h_lane = ctx.load_circuit(art["sppc"], art["pk"], 6)
+        monkeypatch.delenv("SPP_NO_COOP")
+        try:
+            rows_b = workload.withdraw_rows(ctx, big, seed=11) if name == "withdraw" else \
+                workload.audit_rows(ctx, rlwe_pk["a"], rlwe_pk["b"], big, first=7)
+            row_len = h.n_inputs * 32
+            rs = b"".join(rng.randrange(R).to_bytes(32, "big") + rng.randrange(R).to_bytes(32, "big") for _ in range(big))
+            ref_p, ref_w = prove(h_lane, rows_b[:17 * row_len], 17, rs[:17 * 64])
+            for n in (1, 3, 17):
+                p, w = prove(h, rows_b[:n * row_len], n, rs[:n * 64])
+                assert p == ref_p[:n] and w == ref_w[:n], (name, n)
+            p, w = prove(h, rows_b, big, rs)            # > 1024: one lane per proof, blinding multiplied by the lanes
+            assert p[:17] == ref_p and w[:17] == ref_w, name
+            tail_p, tail_w = prove(h, rows_b[(big - 2) * row_len:], 2, rs[(big - 2) * 64:])
+            assert p[-2:] == tail_p and w[-2:] == tail_w, name
+            assert all(ctx.verify_batch(open(art["vk"], "rb").read(), p[:64] + p[-64:], w[:64] + w[-64:]))
+        finally:
+            h.close()
+            h_lane.close()
