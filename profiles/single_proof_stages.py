@@ -8,13 +8,17 @@ from spp import workload
 dev=torch.device("cuda",0)
 tmp=tempfile.mkdtemp()
 pk=json.load(open(os.path.join(ROOT,"tests/golden/rlwe_pk.json")))
-for cid,name in ((1,"withdraw"),(2,"audit")):
+for cid,name in ((1,"withdraw"),(2,"audit"),(5,"withdraw_acir")):
     sppc,pkp,vkp=(os.path.join(tmp,name+e) for e in (".sppc",".pk",".vk"))
-    spp.build_circuit(cid,sppc,aux=(list(pk["a"])+list(pk["b"])) if cid==2 else None)
+    if cid==5:
+        from spp import acir
+        acir.compile_to_sppc(os.path.join(ROOT,"tests","golden","reference_withdraw_acir.json"),sppc)
+    else:
+        spp.build_circuit(cid,sppc,aux=(list(pk["a"])+list(pk["b"])) if cid==2 else None)
     ctx=spp.Context(0); ctx.setup(sppc,b"\x2a"*32,pkp,vkp)
-    for win in (8,0):
+    for win in ((8,0) if cid!=5 else (8,)):
         t0=time.time(); h=ctx.load_circuit(sppc,pkp,win); load=time.time()-t0
-        rows=workload.withdraw_rows(ctx,1) if cid==1 else workload.audit_rows(ctx,pk["a"],pk["b"],1)
+        rows=workload.withdraw_rows(ctx,1) if cid!=2 else workload.audit_rows(ctx,pk["a"],pk["b"],1)
         inp=torch.frombuffer(bytearray(rows),dtype=torch.uint8).to(dev)
         rs=torch.frombuffer(bytearray((R1).to_bytes(32,"big")+(R2).to_bytes(32,"big")),dtype=torch.uint8).to(dev)
         pr=torch.zeros(388,dtype=torch.uint8,device=dev); pw=torch.zeros(h.pw_len,dtype=torch.uint8,device=dev); st=torch.zeros(1,dtype=torch.int32,device=dev)

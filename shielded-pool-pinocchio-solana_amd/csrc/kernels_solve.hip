@@ -14,11 +14,12 @@
 
 namespace spp {
 
+// terms first, first + step, ... of row k without its last k_end_skip terms (first = 0, step = 1: all of them)
 __device__ __forceinline__ Fr dev_row_dot(const DevSparse& m, const Fr* __restrict__ coeffs, uint32_t k, uint32_t k_end_skip,
-                                           const Fr* __restrict__ W, uint32_t P, uint32_t p) {
+                                           const Fr* __restrict__ W, uint32_t P, uint32_t p, uint32_t first = 0, uint32_t step = 1) {
   Fr acc = Fr::zero();
-  const uint32_t b = m.rowptr[k], e = m.rowptr[k + 1] - k_end_skip;
-  for (uint32_t t = b; t < e; t++) {
+  const uint32_t b = m.rowptr[k] + first, e = m.rowptr[k + 1] - k_end_skip;
+  for (uint32_t t = b; t < e; t += step) {
     const uint32_t ci = m.coeff[t];
     Fr w = W[(size_t)m.wire[t] * P + p];
     if (ci & COEFF_ONE) acc = acc + w;
@@ -568,8 +569,33 @@ __global__ void __launch_bounds__(64) k_solve_coop(DevCircuit dc, DevCoop co, Fr
       }
       case COOP_LEVELS:
         for (uint32_t lv = a; lv < b; lv++) {
-          const uint32_t r0 = co.lvl_ptr[lv], r1 = co.lvl_ptr[lv + 1];
-          for (uint32_t r = r0 + lane; r < r1; r += 64) solve_c_row(dc, W, co.lvl_rows[r], P, p);
+          const uint32_t r0 = co.lvl_ptr[lv], r1 = co.lvl_ptr[lv + 1], nr = r1 - r0;
+          // G lanes per row (a power of two, <= 16): the terms of the three linear forms are dealt over them and the partial
+          // sums joined by shuffles -- a level of a compiled (ACIR) program has two or three rows of 40-term forms
+          uint32_t G = 1;
+          while (G < 16 && nr * (G * 2) <= 64) G *= 2;
+          const uint32_t per_pass = 64 / G, sub = lane % G;
+          for (uint32_t r = r0; r < r1; r += per_pass) {           // uniform trip count: every lane reaches the shuffles
+            const uint32_t mine = r + lane / G;
+            const bool live = mine < r1;
+            const uint32_t k = live ? co.lvl_rows[mine] : 0;
+            Fr bv = Fr::zero(), av = Fr::zero(), rest = Fr::zero();
+            const bool square = live && (dc.row_flags[k] & 2);
+            if (live) {
+              bv = dev_row_dot(dc.B, dc.coeffs, k, 0, W, P, p, sub, G);
+              if (!square) av = dev_row_dot(dc.A, dc.coeffs, k, 0, W, P, p, sub, G);
+              rest = dev_row_dot(dc.C, dc.coeffs, k, 1, W, P, p, sub, G);
+            }
+            for (uint32_t off = G >> 1; off >= 1; off >>= 1) {
+              bv = bv + lane_get(bv, lane ^ off);
+              av = av + lane_get(av, lane ^ off);
+              rest = rest + lane_get(rest, lane ^ off);
+            }
+            if (live && sub == 0) {
+              if (square) av = bv;
+              W[(size_t)dc.C.wire[dc.C.rowptr[k + 1] - 1] * P + p] = av * bv - rest;
+            }
+          }
           __syncthreads();
         }
         break;
