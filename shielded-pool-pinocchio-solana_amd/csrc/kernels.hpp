@@ -114,7 +114,10 @@ struct DevCoop {
   const uint32_t* lvl_ptr;    // COOP_LEVELS: rows lvl_rows[lvl_ptr[l] .. lvl_ptr[l+1]) form dependency level l
   const uint32_t* lvl_rows;
 };
-void launch_solve_coop(hipStream_t st, DevCircuit dc, DevCoop co, Fr* W, Fr* scratch, uint32_t item_begin, uint32_t item_end, uint32_t P);
+// independent item ranges of one stretch: track t (blockIdx.y) runs items [begin[t], end[t]); only track 0 may use `scratch`
+static constexpr uint32_t COOP_TRACKS = 4;
+struct CoopTracks { uint32_t n; uint32_t begin[COOP_TRACKS], end[COOP_TRACKS]; };
+void launch_solve_coop(hipStream_t st, DevCircuit dc, DevCoop co, Fr* W, Fr* scratch, CoopTracks tracks, uint32_t P);
 // wide forms of the two data-parallel solver instructions (one lane per (element chunk, proof) instead of one per proof)
 void launch_batch_div(hipStream_t st, DevCircuit dc, Fr* W, Fr* scratch, uint32_t k0, uint32_t n, uint32_t P);
 void launch_count8(hipStream_t st, DevCircuit dc, Fr* W, uint32_t* counters, uint32_t h0, uint32_t n, uint32_t out0, uint32_t P);

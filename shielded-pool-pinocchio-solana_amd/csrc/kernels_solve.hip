@@ -550,9 +550,11 @@ __device__ __forceinline__ void solve_c_row(const DevCircuit& dc, Fr* __restrict
   W[(size_t)out * P + p] = a * b - rest;
 }
 
-__global__ void __launch_bounds__(64) k_solve_coop(DevCircuit dc, DevCoop co, Fr* __restrict__ W, Fr* __restrict__ scratch, uint32_t item,
-                                                   uint32_t item_end, uint32_t P) {
+__global__ void __launch_bounds__(64) k_solve_coop(DevCircuit dc, DevCoop co, Fr* __restrict__ W, Fr* __restrict__ scratch, CoopTracks tracks,
+                                                   uint32_t P) {
   const uint32_t p = blockIdx.x, lane = threadIdx.x;
+  uint32_t item = tracks.begin[blockIdx.y];
+  const uint32_t item_end = tracks.end[blockIdx.y];
   const uint32_t* __restrict__ pr = dc.program;
   for (; item < item_end; item++) {
     const uint32_t kind = co.items[3 * item], a = co.items[3 * item + 1], b = co.items[3 * item + 2];
@@ -617,9 +619,9 @@ __global__ void __launch_bounds__(64) k_solve_coop(DevCircuit dc, DevCoop co, Fr
     __syncthreads();   // the next item reads wires other lanes have just written
   }
 }
-void launch_solve_coop(hipStream_t st, DevCircuit dc, DevCoop co, Fr* W, Fr* scratch, uint32_t item_begin, uint32_t item_end, uint32_t P) {
-  if (item_begin >= item_end || P == 0) return;
-  hipLaunchKernelGGL(k_solve_coop, dim3(P), dim3(64), 0, st, dc, co, W, scratch, item_begin, item_end, P);
+void launch_solve_coop(hipStream_t st, DevCircuit dc, DevCoop co, Fr* W, Fr* scratch, CoopTracks tracks, uint32_t P) {
+  if (tracks.n == 0 || P == 0) return;
+  hipLaunchKernelGGL(k_solve_coop, dim3(P, tracks.n), dim3(64), 0, st, dc, co, W, scratch, tracks, P);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -52,7 +52,8 @@ struct PendingTable {
 struct SolveStep {
   enum Kind { SEQ, BATCH_DIV, COUNT8, COMMIT } kind;
   uint32_t a = 0, b = 0, c = 0;   // SEQ: [pc_begin, pc_end) ; BATCH_DIV: k0, n ; COUNT8: h0, n, out0
-  uint32_t item0 = 0, item1 = 0;  // SEQ: the same stretch as items of the cooperative solver (small batches)
+  // SEQ: the same stretch as items of the cooperative solver (small batches), dealt over independent tracks (coop_plan)
+  uint32_t ntracks = 0, tr_begin[COOP_TRACKS] = {}, tr_end[COOP_TRACKS] = {};
 };
 // batches up to this size are solved by one wave per proof (k_solve_coop); above it the wave-per-64-proofs solver has the
 // better throughput (a cooperative wave runs ~1/3 of the dependent instructions, but 64 times as many waves)
@@ -71,6 +72,7 @@ struct spp_circuit {
   DevCoop coop{};
   bool no_coop = false;           // SPP_NO_COOP=1 (diagnostic): always the one-lane-per-proof solver
   bool trace_items = false;       // SPP_COOP_TRACE=1 (diagnostic): one launch per item of the cooperative solver
+  bool one_track = false;         // SPP_COOP_ONE_TRACK=1 (diagnostic): the independent tracks of a stretch one after the other
   uint32_t row_r = 0, row_s = 0, row_rs = 0, n_rows = 0;
   uint64_t table_bytes = 0;
   MsmSet<Fq> A, B1, K, Z, CB, CS;
@@ -96,12 +98,16 @@ static int own_upload(spp_circuit* c, T** dst, const std::vector<T>& src) {
 // Item list of the cooperative solver (kernels_solve.hip, k_solve_coop) for every sequential stretch of the schedule.
 // Nothing here changes what is computed: permutations become their lane-parallel form, runs of SOLVE_C rows are ordered
 // by dependency level (level of a row = 1 + the highest level among the rows of the run that write one of its inputs),
-// runs of independent BITS / LIMBS8 / INV_H instructions go one per lane, the rest stays on lane 0.
+// runs of independent BITS / LIMBS8 / INV_H instructions go one per lane, the rest stays on lane 0.  Items that share no
+// wire (directly or through other items of the stretch) form independent components; the components are dealt over up to
+// COOP_TRACKS waves per proof, longest first (the Merkle chain beside the key derivation; the ciphertext sponge beside the
+// rest of the audit circuit).  Components that use the per-proof scratch rows stay together on track 0.
 static int coop_plan(spp_circuit* c) {
   const Circuit& circ = c->circ;
   const auto& pr = circ.program;
+  struct Item { uint32_t kind, a, b; };
   std::vector<uint32_t> items, par, lvl_ptr{0}, lvl_rows;
-  std::vector<uint32_t> level_of(circ.n_wires + 3, 0), stamp(circ.n_wires + 3, 0);
+  std::vector<uint32_t> level_of(circ.n_wires + 3, 0), stamp(circ.n_wires + 3, 0), writer(circ.n_wires + 3, 0);
   uint32_t epoch = 0;
   auto op_len = [&](size_t pc) -> uint32_t {
     switch (pr[pc]) {
@@ -114,11 +120,59 @@ static int coop_plan(spp_circuit* c) {
     }
   };
   auto is_par_op = [&](uint32_t op) { return op == OP_BITS || op == OP_LIMBS8 || op == OP_INV_H; };
+  // wires an instruction reads / writes, a rough cost in microseconds of a lone wave, whether it uses the scratch rows
+  struct RW { std::vector<uint32_t> rd, wr; double cost = 0; bool scratch = false; };
+  auto row_rd = [&](RW& x, const Sparse& m, uint32_t k, uint32_t skip_last) {
+    for (uint32_t t = m.rowptr[k]; t + skip_last < m.rowptr[k + 1]; t++) x.rd.push_back(m.terms[t].wire);
+  };
+  auto solve_c_rw = [&](RW& x, uint32_t k) {
+    row_rd(x, circ.A, k, 0); row_rd(x, circ.B, k, 0); row_rd(x, circ.C, k, 1);
+    x.wr.push_back(circ.C.terms[circ.C.rowptr[k + 1] - 1].wire);
+  };
+  auto div_rw = [&](RW& x, uint32_t k) {
+    row_rd(x, circ.B, k, 0); row_rd(x, circ.C, k, 0);
+    x.wr.push_back(circ.A.terms[circ.A.rowptr[k]].wire);
+  };
+  auto op_rw = [&](RW& x, size_t pc, bool coop_form) {
+    switch (pr[pc]) {
+      case OP_SOLVE_C: solve_c_rw(x, pr[pc + 1]); x.cost += 5; break;
+      case OP_SOLVE_A: div_rw(x, pr[pc + 1]); x.cost += 60; x.scratch = true; break;
+      case OP_BATCH_DIV:
+        for (uint32_t k = 0; k < pr[pc + 2]; k++) div_rw(x, pr[pc + 1] + k);
+        x.cost += 60 + 10.0 * pr[pc + 2]; x.scratch = true;
+        break;
+      case OP_BITS: case OP_LIMBS8:
+        row_rd(x, circ.H, pr[pc + 1], 0);
+        for (uint32_t i = 0; i < pr[pc + 2]; i++) x.wr.push_back(pr[pc + 3] + i);
+        x.cost += 5 + 0.2 * pr[pc + 2];
+        break;
+      case OP_INV_H: row_rd(x, circ.H, pr[pc + 1], 0); x.wr.push_back(pr[pc + 2]); x.cost += 40; break;
+      case OP_POSEIDON: {
+        const uint32_t t = pr[pc + 1], nsbox = 8 * t + (t == 3 ? 57 : 60);
+        for (uint32_t i = 0; i < t; i++) row_rd(x, circ.H, pr[pc + 2] + i, 0);
+        for (uint32_t i = 0; i < 4 * nsbox; i++) x.wr.push_back(pr[pc + 3] + i);
+        x.cost += coop_form ? 175 : 450;
+        break;
+      }
+      case OP_POSEIDON2:
+        for (uint32_t i = 0; i < 4; i++) row_rd(x, circ.H, pr[pc + 1] + i, 0);
+        for (uint32_t i = 0; i < 4 * 88; i++) x.wr.push_back(pr[pc + 2] + i);
+        x.cost += coop_form ? 185 : 480;
+        break;
+      case OP_GRUMPKIN:
+        for (uint32_t i = 0; i < pr[pc + 2]; i++) x.rd.push_back(pr[pc + 1] + i);
+        for (uint32_t i = 0; i < pr[pc + 4]; i++) x.wr.push_back(pr[pc + 5 + i]);
+        x.cost += coop_form ? 300 : 1800;
+        x.scratch = x.scratch || !coop_form;
+        break;
+      default: break;
+    }
+  };
   for (SolveStep& st : c->schedule) {
     if (st.kind != SolveStep::SEQ) continue;
-    st.item0 = (uint32_t)(items.size() / 3);
+    std::vector<Item> its;
     size_t pc = st.a, seq0 = st.a;
-    auto push = [&](uint32_t kind, uint32_t a, uint32_t b) { items.push_back(kind); items.push_back(a); items.push_back(b); };
+    auto push = [&](uint32_t kind, uint32_t a, uint32_t b) { its.push_back({kind, a, b}); };
     auto flush = [&](size_t end) {
       if (end > seq0) push(COOP_SEQ, (uint32_t)seq0, (uint32_t)end);
     };
@@ -193,7 +247,60 @@ static int coop_plan(spp_circuit* c) {
       }
     }
     flush(st.b);
-    st.item1 = (uint32_t)(items.size() / 3);
+
+    // ---- independent components of this stretch -> tracks ----
+    const size_t n = its.size();
+    std::vector<RW> rw(n);
+    for (size_t i = 0; i < n; i++) {
+      const Item& it = its[i];
+      switch (it.kind) {
+        case COOP_SEQ:
+          for (size_t q = it.a; q < it.b; q += op_len(q)) op_rw(rw[i], q, false);
+          break;
+        case COOP_PAR:
+          for (uint32_t g = it.a; g < it.b; g++) op_rw(rw[i], par[2 * g], false);
+          rw[i].cost = 10 + rw[i].cost / 32;
+          break;
+        case COOP_LEVELS:
+          for (uint32_t r = lvl_ptr[it.a]; r < lvl_ptr[it.b]; r++) solve_c_rw(rw[i], lvl_rows[r]);
+          rw[i].cost = 4.5 * (it.b - it.a);
+          break;
+        default: op_rw(rw[i], it.a, true); break;
+      }
+    }
+    std::vector<uint32_t> parent(n);
+    for (size_t i = 0; i < n; i++) parent[i] = (uint32_t)i;
+    auto find = [&](uint32_t x) { while (parent[x] != x) x = parent[x] = parent[parent[x]]; return x; };
+    epoch++;
+    for (size_t i = 0; i < n; i++) {
+      for (uint32_t w : rw[i].rd)
+        if (stamp[w] == epoch) { const uint32_t ra = find((uint32_t)i), rb = find(writer[w]); if (ra != rb) parent[ra] = rb; }
+      for (uint32_t w : rw[i].wr) { stamp[w] = epoch; writer[w] = (uint32_t)i; }
+    }
+    std::vector<double> comp_cost(n, 0.0);
+    std::vector<char> comp_scratch(n, 0);
+    for (size_t i = 0; i < n; i++) { const uint32_t r = find((uint32_t)i); comp_cost[r] += rw[i].cost; comp_scratch[r] |= rw[i].scratch; }
+    std::vector<uint32_t> roots;
+    for (size_t i = 0; i < n; i++) if (find((uint32_t)i) == i) roots.push_back((uint32_t)i);
+    std::sort(roots.begin(), roots.end(), [&](uint32_t x, uint32_t y) { return comp_cost[x] > comp_cost[y]; });
+    double load[COOP_TRACKS] = {};
+    std::vector<uint32_t> track_of(n, 0);
+    for (uint32_t r : roots) if (comp_scratch[r]) { track_of[r] = 0; load[0] += comp_cost[r]; }
+    for (uint32_t r : roots) {
+      if (comp_scratch[r]) continue;
+      uint32_t best = 0;
+      for (uint32_t t = 1; t < COOP_TRACKS; t++) if (load[t] < load[best]) best = t;
+      track_of[r] = best;
+      load[best] += comp_cost[r];
+    }
+    st.ntracks = 0;
+    for (uint32_t t = 0; t < COOP_TRACKS; t++) {
+      st.tr_begin[t] = (uint32_t)(items.size() / 3);
+      for (size_t i = 0; i < n; i++)
+        if (track_of[find((uint32_t)i)] == t) { items.push_back(its[i].kind); items.push_back(its[i].a); items.push_back(its[i].b); }
+      st.tr_end[t] = (uint32_t)(items.size() / 3);
+      if (st.tr_end[t] > st.tr_begin[t]) st.ntracks = t + 1;
+    }
   }
   if (items.empty()) items.assign(3, 0);
   if (par.empty()) par.assign(2, 0);
@@ -638,6 +745,7 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
     const bool trace_ops = getenv("SPP_SOLVE_TRACE") != nullptr;
     c->no_coop = getenv("SPP_NO_COOP") != nullptr || trace_ops;
     c->trace_items = getenv("SPP_COOP_TRACE") != nullptr;
+    c->one_track = getenv("SPP_COOP_ONE_TRACK") != nullptr;
     uint32_t prev_op = OP_END;
     while (pc < pr.size() && pr[pc] != OP_END) {
       if (trace_ops && pr[pc] != prev_op) {
@@ -902,9 +1010,25 @@ static int prove_on_device(spp_circuit* c, Workspace& w, uint32_t P, const uint8
   for (const SolveStep& s : c->schedule) {
     switch (s.kind) {
       case SolveStep::SEQ:
-        if (P <= COOP_MAX_BATCH && !c->no_coop && c->trace_items)
-          for (uint32_t it = s.item0; it < s.item1; it++) launch_solve_coop(st, c->dc, c->coop, w.W, w.scratch, it, it + 1, P);
-        else if (P <= COOP_MAX_BATCH && !c->no_coop) launch_solve_coop(st, c->dc, c->coop, w.W, w.scratch, s.item0, s.item1, P);
+        if (P <= COOP_MAX_BATCH && !c->no_coop && c->trace_items) {
+          for (uint32_t t = 0; t < s.ntracks; t++)
+            for (uint32_t it = s.tr_begin[t]; it < s.tr_end[t]; it++) {
+              CoopTracks one{};
+              one.n = 1; one.begin[0] = it; one.end[0] = it + 1;
+              launch_solve_coop(st, c->dc, c->coop, w.W, w.scratch, one, P);
+            }
+        } else if (P <= COOP_MAX_BATCH && !c->no_coop) {
+          CoopTracks tr{};
+          tr.n = c->one_track ? 1 : s.ntracks;
+          for (uint32_t t = 0; t < s.ntracks; t++) { tr.begin[t] = s.tr_begin[t]; tr.end[t] = s.tr_end[t]; }
+          if (c->one_track) {   // SPP_COOP_ONE_TRACK=1 (diagnostic): the tracks one after the other
+            for (uint32_t t = 0; t < s.ntracks; t++) {
+              CoopTracks one{};
+              one.n = 1; one.begin[0] = s.tr_begin[t]; one.end[0] = s.tr_end[t];
+              launch_solve_coop(st, c->dc, c->coop, w.W, w.scratch, one, P);
+            }
+          } else launch_solve_coop(st, c->dc, c->coop, w.W, w.scratch, tr, P);
+        }
         else launch_solve(st, c->dc, w.W, w.scratch, s.a, s.b, P);
         break;
       case SolveStep::BATCH_DIV: launch_batch_div(st, c->dc, w.W, w.scratch, s.a, s.b, P); break;
