@@ -208,14 +208,55 @@ static int coop_plan(spp_circuit* c) {
           rows.push_back({lv, k});
           max_level = std::max(max_level, lv);
         }
-        std::stable_sort(rows.begin(), rows.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
-        const uint32_t l0 = (uint32_t)lvl_ptr.size() - 1;
-        size_t i = 0;
-        for (uint32_t lv = 0; lv <= max_level; lv++) {
-          while (i < rows.size() && rows[i].first == lv) lvl_rows.push_back(rows[i++].second);
-          lvl_ptr.push_back((uint32_t)lvl_rows.size());
+        // rows of the run that share no wire written inside it are independent of each other: one LEVELS item per connected
+        // component (small ones lumped together), so that the tracks below can take them apart (a compiled program keeps the
+        // key derivation and the hash chain in the same run of rows)
+        std::vector<uint32_t> rp(rows.size());
+        for (size_t i = 0; i < rows.size(); i++) rp[i] = (uint32_t)i;
+        auto rfind = [&](uint32_t x) { while (rp[x] != x) x = rp[x] = rp[rp[x]]; return x; };
+        epoch++;
+        for (size_t i = 0; i < rows.size(); i++) {
+          const uint32_t k = rows[i].second;
+          auto link = [&](const Sparse& m, uint32_t skip_last) {
+            for (uint32_t t = m.rowptr[k]; t + skip_last < m.rowptr[k + 1]; t++) {
+              const uint32_t w = m.terms[t].wire;
+              if (stamp[w] == epoch) { const uint32_t ra = rfind((uint32_t)i), rb = rfind(writer[w]); if (ra != rb) rp[ra] = rb; }
+            }
+          };
+          link(circ.A, 0); link(circ.B, 0); link(circ.C, 1);
+          const uint32_t out = circ.C.terms[circ.C.rowptr[k + 1] - 1].wire;
+          stamp[out] = epoch;
+          writer[out] = (uint32_t)i;
         }
-        push(COOP_LEVELS, l0, l0 + max_level + 1);
+        std::vector<uint32_t> comp_size(rows.size(), 0), comp_id(rows.size(), 0);
+        for (size_t i = 0; i < rows.size(); i++) comp_size[rfind((uint32_t)i)]++;
+        const uint32_t MISC = 0xffffffffu;
+        std::vector<uint32_t> comp_order;     // big components in order of first appearance, then the lump of small ones
+        bool any_misc = false;
+        for (size_t i = 0; i < rows.size(); i++) {
+          const uint32_t r = rfind((uint32_t)i);
+          if (comp_size[r] < 32) { comp_id[i] = MISC; any_misc = true; continue; }
+          comp_id[i] = r;
+          if (std::find(comp_order.begin(), comp_order.end(), r) == comp_order.end()) comp_order.push_back(r);
+        }
+        if (any_misc) comp_order.push_back(MISC);
+        std::vector<size_t> order(rows.size());
+        for (size_t i = 0; i < rows.size(); i++) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return rows[x].first < rows[y].first; });
+        for (uint32_t cid : comp_order) {
+          const uint32_t l0 = (uint32_t)lvl_ptr.size() - 1;
+          uint32_t cur = 0xffffffffu;
+          for (size_t oi : order) {
+            if (comp_id[oi] != cid) continue;
+            if (rows[oi].first != cur) {
+              if (cur != 0xffffffffu) lvl_ptr.push_back((uint32_t)lvl_rows.size());
+              cur = rows[oi].first;
+            }
+            lvl_rows.push_back(rows[oi].second);
+          }
+          lvl_ptr.push_back((uint32_t)lvl_rows.size());
+          push(COOP_LEVELS, l0, (uint32_t)lvl_ptr.size() - 1);
+        }
         pc = e;
         seq0 = pc;
       } else if (is_par_op(op)) {
