@@ -16,7 +16,7 @@ for cid,name in ((1,"withdraw"),(2,"audit"),(5,"withdraw_acir")):
     else:
         spp.build_circuit(cid,sppc,aux=(list(pk["a"])+list(pk["b"])) if cid==2 else None)
     ctx=spp.Context(0); ctx.setup(sppc,b"\x2a"*32,pkp,vkp)
-    for win in ((8,0) if cid!=5 else (8,)):
+    for win in ((8,0) if (cid!=5 and not os.environ.get('SPP_STAGES_QUICK')) else (8,)):
         t0=time.time(); h=ctx.load_circuit(sppc,pkp,win); load=time.time()-t0
         rows=workload.withdraw_rows(ctx,1) if cid!=2 else workload.audit_rows(ctx,pk["a"],pk["b"],1)
         inp=torch.frombuffer(bytearray(rows),dtype=torch.uint8).to(dev)
