@@ -16,6 +16,7 @@
 #include <hip/hip_ext.h>
 #include "kernels.hpp"
 #include <algorithm>
+#include <cstdlib>
 #include "f29.hpp"
 
 namespace spp {
@@ -42,7 +43,12 @@ uint32_t msm_slices_split(uint32_t N, uint32_t P, uint32_t Q) {
 
 // enough (slice, proof) lanes to fill 256 CUs x 4 SIMDs x ~4 waves, but at least 4 bases per slice
 uint32_t msm_slices(uint32_t N, uint32_t P) {
-  const uint32_t target_lanes = 256u * 4u * 4u * 64u;
+  static const uint32_t waves_per_simd = [] {   // SPP_MSM_WAVES (experiment): lanes launched = 256 CUs x 4 SIMDs x this x 64
+    const char* e = getenv("SPP_MSM_WAVES");
+    const int v = e ? atoi(e) : 4;
+    return (uint32_t)(v >= 1 && v <= 8 ? v : 4);
+  }();
+  const uint32_t target_lanes = 256u * 4u * waves_per_simd * 64u;
   uint32_t S = (target_lanes + P - 1) / P;
   uint32_t maxS = (N + 3) / 4;
   if (maxS == 0) maxS = 1;

@@ -8,10 +8,30 @@ Layout (gnark 0.14, decoded from the reference's own file):
          {Type, GnarkVersion, ScalarField, NbConstraints, NbInternalVariables, Public[], Secret[], Blueprints[],
           CommitmentInfo, MHintsDependencies, GkrInfo, Logs, DebugInfo, MDebug, SymbolTable ...}
   then   u64 LE count . count x 32 B   the coefficient table, little-endian Montgomery limbs (entry 1 = R mod r)
-This module decodes the header, the CBOR body and the coefficient table -- everything that pins the DIMENSIONS and wire
-naming of the reference's constraint system.  The three integer streams (constraint levels, instructions, calldata) are
-returned as raw bytes: their compression (github.com/ronanh/intcomp, third-party, absent from the reference) is not decoded,
-so this repository cannot yet re-evaluate the reference's own R1CS; see DESIGN.md section 8.
+This module decodes all of it: header, CBOR body, coefficient table and the three integer streams, i.e. the reference's
+whole constraint system -- 12 493 instructions (12 452 R1C rows + 41 hint calls of 9 kinds) in 657 solver levels.
+
+Stream formats (third-party github.com/ronanh/intcomp as called by gnark 0.14; neither is in the reference tree, so the
+layout below was worked out from the reference's own file and is pinned by the invariants tests/test_acir_ccs.py checks:
+every instruction id exactly once over the levels, constraint offsets ending at NbConstraints, wire offsets ending at the
+wire count, calldata offsets equal to the running sum of the calldata record lengths):
+  levels        u64 nLevels, then per level: u64 nWords, one uint32 chunk (sorted instruction ids)
+  instructions  four chunks, each u64 nWords + chunk: blueprint id, constraint offset, wire offset (uint32 chunks) and the
+                calldata offset (uint64 chunk, nWords counts 8-byte words)
+  calldata      u64 count, then `count` LEB128 values: per instruction [len, ...]
+  chunk         [bin-packed section] [var-byte section], both optional
+    bin-packed  count (multiple of 128; 256 for uint64), section length in words, first value, then per block of 128 (256)
+                a header word with four bytes (most significant first), one per group of 32 (64) values: bit 7 = zig-zag
+                deltas, bits 0-6 = width b; followed by the groups' deltas packed LSB-first in b words each
+    var-byte    count, section length, the values' deltas (the first one from zero, not from the packed section) as LEB128
+                bytes stored most-significant-byte-first in each word, padded with 0x80; one trailing word = the length
+R1C calldata: [len, nL, nR, nO, (coefficient id, wire id) x (nL + nR + nO)]; hint calldata: [len, hint id, nInputs,
+{nTerms, (coefficient id, wire id | 0xffffffff = constant) x nTerms} x nInputs, first output wire, end].
+
+`solve_partial` runs gnark's solver loop over the decoded system on a witness of the secret wires (the ACIR witnesses):
+an R1C row with one unknown wire defines it, the standard hints are restated here; the three hints whose code is not
+available (emulated.mulHint and Sunspot's two Grumpkin scalar-decomposition hints, one call each) leave their outputs and
+whatever depends on them unknown.  Every row that can be evaluated is checked.
 """
 import struct
 
@@ -139,3 +159,278 @@ def load_ccs(path):
 def coefficient(c, i):
     """canonical value of coefficient table entry i (stored as a * 2^256 mod r)"""
     return c.coefficients_mont[i] * MONT_R_INV % R
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the three integer streams
+# ---------------------------------------------------------------------------------------------------------------------
+def _unzigzag(v):
+    return (v >> 1) ^ -(v & 1)
+
+
+def _leb128(bs, i):
+    v = sh = 0
+    while True:
+        b = bs[i]
+        i += 1
+        v |= (b & 0x7F) << sh
+        sh += 7
+        if not b & 0x80:
+            return v, i
+
+
+def decode_chunk(words, bits=32):
+    """One intcomp chunk (list of 32- or 64-bit words) -> list of values.  See the module docstring for the layout."""
+    blk = 128 if bits == 32 else 256
+    grp = blk // 4
+    mask_v = (1 << bits) - 1
+    half = 0xFFFFFFFF
+    pos, out = 0, []
+    first = words[0] & half if bits == 64 else words[0]
+    if words and first >= blk and first % blk == 0:
+        if bits == 64:
+            count, length, prev, p = words[0] & half, words[0] >> 32, words[1], 2
+        else:
+            count, length, prev, p = words[0], words[1], words[2], 3
+        for _ in range(count // blk):
+            header = words[p]
+            p += 1
+            for sh in (24, 16, 8, 0):
+                hb = (header >> sh) & 0xFF
+                nb, zz = hb & 0x7F, hb >> 7
+                nw = nb * grp // bits
+                acc = 0
+                for i in range(nw):
+                    acc |= words[p + i] << (bits * i)
+                p += nw
+                m = (1 << nb) - 1
+                for k in range(grp):
+                    d = (acc >> (k * nb)) & m
+                    prev = (prev + (_unzigzag(d) if zz else d)) & mask_v
+                    out.append(prev)
+        if p != length:
+            raise ValueError("bin-packed section ends at word %d, header says %d" % (p, length))
+        pos = p
+    if pos < len(words):
+        if bits == 64:
+            count, length = words[pos] & half, words[pos] >> 32
+        else:
+            count, length = words[pos], words[pos + 1]
+        data0 = pos + (1 if bits == 64 else 2)
+        bs = b"".join(struct.pack(">Q" if bits == 64 else ">I", x) for x in words[data0:pos + length])
+        i, prev = 0, 0
+        for _ in range(count):
+            d, i = _leb128(bs, i)
+            prev = (prev + d) & mask_v
+            out.append(prev)
+        if any(b != 0x80 for b in bs[i:]) or pos + length + 1 != len(words) or words[pos + length] != length:
+            raise ValueError("var-byte section: bad padding or trailer")
+    return out
+
+
+def _u32s(b):
+    return list(struct.unpack_from("<%dI" % (len(b) // 4), b, 0))
+
+
+def decode_levels(c):
+    """list of levels, each the sorted instruction ids that gnark's solver may run in parallel"""
+    w = _u32s(c.levels_raw)
+    n = w[0] | w[1] << 32
+    pos, levels = 2, []
+    for _ in range(n):
+        k = w[pos] | w[pos + 1] << 32
+        levels.append(decode_chunk(w[pos + 2:pos + 2 + k]))
+        pos += 2 + k
+    if pos != len(w):
+        raise ValueError("levels stream: %d words left" % (len(w) - pos))
+    return levels
+
+
+def decode_instructions(c):
+    """(blueprint id, constraint offset, wire offset, calldata offset) columns, one entry per instruction"""
+    w = _u32s(c.instructions_raw)
+    pos, cols = 0, []
+    for _ in range(3):
+        k = w[pos] | w[pos + 1] << 32
+        cols.append(decode_chunk(w[pos + 2:pos + 2 + k]))
+        pos += 2 + k
+    k = w[pos] | w[pos + 1] << 32
+    q = [w[pos + 2 + 2 * i] | w[pos + 3 + 2 * i] << 32 for i in range(k)]
+    cols.append(decode_chunk(q, 64))
+    if pos + 2 + 2 * k != len(w) or len({len(x) for x in cols}) != 1:
+        raise ValueError("instructions stream: inconsistent columns")
+    return cols
+
+
+def decode_calldata(c):
+    n = struct.unpack_from("<Q", c.calldata_raw, 0)[0]
+    out, i = [], 8
+    for _ in range(n):
+        v, i = _leb128(c.calldata_raw, i)
+        out.append(v)
+    if i != len(c.calldata_raw):
+        raise ValueError("calldata stream: %d bytes left" % (len(c.calldata_raw) - i))
+    return out
+
+
+CONST_WIRE = 0xFFFFFFFF
+BLUEPRINT_HINT, BLUEPRINT_R1C = 0, 1
+
+
+class System:
+    """the decoded constraint system: rows[k] = (L, R, O) term lists [(coefficient, wire)], hints = [(instruction, hint id, name,
+    inputs [[(coefficient, wire | CONST_WIRE)]], first output wire, end)], levels, per-instruction columns"""
+
+
+def decode_system(c):
+    s = System()
+    s.levels = decode_levels(c)
+    s.blueprint, s.constraint_offset, s.wire_offset, s.calldata_offset = decode_instructions(c)
+    cd = s.calldata = decode_calldata(c)
+    coef = [v * MONT_R_INV % R for v in c.coefficients_mont]
+    names = c.meta["MHintsDependencies"]
+    s.rows, s.row_instruction, s.hints = [], [], []
+    s.kind = []          # per instruction: ("r1c", row index) or ("hint", index into hints)
+    for k, (bp, off) in enumerate(zip(s.blueprint, s.calldata_offset)):
+        ln = cd[off]
+        if bp == BLUEPRINT_R1C:
+            nl, nr, no = cd[off + 1:off + 4]
+            if ln != 4 + 2 * (nl + nr + no) or s.constraint_offset[k] != len(s.rows):
+                raise ValueError("instruction %d: bad R1C record" % k)
+            p = off + 4
+            terms = [(coef[cd[p + 2 * i]], cd[p + 2 * i + 1]) for i in range(nl + nr + no)]
+            s.rows.append((terms[:nl], terms[nl:nl + nr], terms[nl + nr:]))
+            s.row_instruction.append(k)
+            s.kind.append(("r1c", len(s.rows) - 1))
+        elif bp == BLUEPRINT_HINT:
+            hid, nin = cd[off + 1], cd[off + 2]
+            p, ins = off + 3, []
+            for _ in range(nin):
+                nt = cd[p]
+                ins.append([(coef[cd[p + 1 + 2 * i]], cd[p + 2 + 2 * i]) for i in range(nt)])
+                p += 1 + 2 * nt
+            o0, o1 = cd[p], cd[p + 1]
+            if p + 2 != off + ln or o1 != s.wire_offset[k]:      # the wire-offset column holds the offset AFTER the instruction
+                raise ValueError("instruction %d: bad hint record" % k)
+            s.hints.append((k, hid, names[hid], ins, o0, o1))
+            s.kind.append(("hint", len(s.hints) - 1))
+        else:
+            raise ValueError("instruction %d: blueprint %d" % (k, bp))
+    s.n_wires = len(c.public) + len(c.secret) + c.n_internal
+    return s
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# gnark's solver loop on the decoded system
+# ---------------------------------------------------------------------------------------------------------------------
+UNSUPPORTED_HINTS = ("emulated.mulHint", "sw-grumpkin.decompose", "sw-grumpkin.decomposeScalar")
+
+
+def _hint_outputs(name, ins, n_out, challenge):
+    """The standard gnark hints of this system, restated from their documented behaviour (gnark 0.14: std/rangecheck,
+    std/math/bits, constraint/solver, std/internal/logderivarg, internal/hints, frontend/cs)."""
+    short = name.rsplit("/", 1)[-1]
+    if short == "bits.nBits":                               # bits of the value, least significant first
+        return [(ins[0] >> i) & 1 for i in range(n_out)]
+    if short == "rangecheck.DecomposeHint":                 # inputs: total width, limb width, value -> limbs
+        width = ins[1]
+        return [(ins[2] >> (width * i)) & ((1 << width) - 1) for i in range(n_out)]
+    if short == "solver.InvZeroHint":                       # 1/x, or 0 for 0
+        return [pow(v, -1, R) if v else 0 for v in ins][:n_out]
+    if short == "logderivarg.countHint":                    # inputs: row width, table size, table rows, queries -> multiplicities
+        nb_vals, nb_table = ins[0], ins[1]
+        table = {}
+        flat = ins[2:]
+        for i in range(nb_table):
+            table.setdefault(tuple(flat[i * nb_vals:(i + 1) * nb_vals]), i)
+        counts = [0] * nb_table
+        q = flat[nb_table * nb_vals:]
+        for i in range(len(q) // nb_vals):
+            counts[table[tuple(q[i * nb_vals:(i + 1) * nb_vals])]] += 1
+        return counts[:n_out]
+    if short == "hints.Randomize":                          # any value satisfies the rows that use it
+        return [challenge] * n_out
+    if short == "cs.Bsb22CommitmentComputePlaceholder":     # the commitment challenge: any value satisfies the rows
+        return [challenge] * n_out
+    return None
+
+
+def solve_partial(system, c, public_inputs, secret_by_name, challenge=0x5EED):
+    """-> (wires list with None for unknown, stats dict).  public_inputs: the five values after the constant wire;
+    secret_by_name: {"__witness_<i>": value}."""
+    w = [None] * system.n_wires
+    w[0] = 1
+    for i, v in enumerate(public_inputs):
+        w[1 + i] = v % R
+    base = len(c.public)
+    for i, nm in enumerate(c.secret):
+        w[base + i] = secret_by_name[nm] % R
+    stats = {"rows_checked": 0, "rows_solved": 0, "rows_unsatisfied": [], "rows_skipped": 0, "hints_run": 0, "hints_skipped": []}
+
+    def lin(terms):
+        s, unknown = 0, []
+        for cf, wi in terms:
+            if w[wi] is None:
+                unknown.append((cf, wi))
+            else:
+                s += cf * w[wi]
+        return s % R, unknown
+
+    for level in system.levels:
+        for k in level:
+            kind, idx = system.kind[k]
+            if kind == "hint":
+                _, _, name, ins, o0, o1 = system.hints[idx]
+                vals, ok = [], True
+                for terms in ins:
+                    s = 0
+                    for cf, wi in terms:
+                        if wi == CONST_WIRE:
+                            s += cf
+                        elif w[wi] is None:
+                            ok = False
+                        else:
+                            s += cf * w[wi]
+                    vals.append(s % R)
+                outs = _hint_outputs(name, vals, o1 - o0, challenge) if ok else None
+                if outs is None:
+                    stats["hints_skipped"].append((k, name.rsplit("/", 1)[-1]))
+                    continue
+                for i, v in enumerate(outs):
+                    w[o0 + i] = v % R
+                stats["hints_run"] += 1
+                continue
+            L, Rr, O = system.rows[idx]
+            (l, ul), (r, ur), (o, uo) = lin(L), lin(Rr), lin(O)
+            unknown = {wi for _, wi in ul + ur + uo}
+            if not unknown:
+                stats["rows_checked"] += 1
+                if l * r % R != o:
+                    stats["rows_unsatisfied"].append(idx)
+                continue
+            if len(unknown) > 1:
+                stats["rows_skipped"] += 1
+                continue
+            wi = next(iter(unknown))
+            cf = lambda u: sum(c_ for c_, x in u if x == wi) % R
+            if uo and not ul and not ur:          # l * r = o0 + cf * x
+                if cf(uo) == 0:
+                    stats["rows_skipped"] += 1
+                    continue
+                w[wi] = (l * r - o) * pow(cf(uo), -1, R) % R
+            elif ul and not ur and not uo:        # (l0 + cf * x) * r = o
+                if r == 0 or cf(ul) == 0:
+                    stats["rows_skipped"] += 1
+                    continue
+                w[wi] = (o * pow(r, -1, R) - l) * pow(cf(ul), -1, R) % R
+            elif ur and not ul and not uo:
+                if l == 0 or cf(ur) == 0:
+                    stats["rows_skipped"] += 1
+                    continue
+                w[wi] = (o * pow(l, -1, R) - r) * pow(cf(ur), -1, R) % R
+            else:                                  # the unknown on two sides: not a shape gnark's solver accepts either
+                stats["rows_skipped"] += 1
+                continue
+            stats["rows_solved"] += 1
+    stats["wires_known"] = sum(v is not None for v in w)
+    return w, stats

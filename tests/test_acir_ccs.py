@@ -147,6 +147,72 @@ def test_ccs_container_matches_the_recorded_facts():
     assert sorted(int(s.split("_")[-1]) for s in c.secret) == sorted(k for k in w if k >= 5)
 
 
+def test_ccs_streams_decode_to_the_whole_constraint_system():
+    """The three compressed streams (levels, instructions, calldata) of the reference's .ccs decode to a consistent system:
+    12 493 instructions = 12 452 R1C rows + 41 hint calls of the 9 kinds the CBOR body names, 657 solver levels that hold every
+    instruction exactly once, constraint / wire / calldata offsets that add up to the recorded dimensions."""
+    from spp import ccs
+    import collections
+    c = ccs.load_ccs(os.path.join(GOLDEN, "reference_withdraw.ccs"))
+    s = ccs.decode_system(c)
+    n = len(s.blueprint)
+    assert n == 12493 and len(s.rows) == c.n_constraints == 12452 and len(s.hints) == 41 and s.n_wires == 12939
+    assert len(s.levels) == 657 and [len(l) for l in s.levels[:6]] == [6250, 4643, 398, 6, 2, 492]
+    flat = [k for l in s.levels for k in l]
+    assert sorted(flat) == list(range(n)) and all(a < b for l in s.levels for a, b in zip(l, l[1:]))
+    assert collections.Counter(s.blueprint) == {ccs.BLUEPRINT_R1C: 12452, ccs.BLUEPRINT_HINT: 41}
+    # offsets: constraints count the R1C rows, wires end at the wire count, calldata offsets are the running record lengths
+    assert s.constraint_offset[0] == 0 and s.constraint_offset[-1] == 12451 and s.wire_offset[0] == 6190 and s.wire_offset[-1] == 12939
+    assert all(a <= b for a, b in zip(s.wire_offset, s.wire_offset[1:]))
+    assert s.calldata_offset[0] == 0 and len(s.calldata) == 262332
+    assert all(s.calldata_offset[k] + s.calldata[s.calldata_offset[k]] == (s.calldata_offset[k + 1] if k + 1 < n else len(s.calldata)) for k in range(n))
+    by_name = collections.Counter(h[2].rsplit("/", 1)[-1] for h in s.hints)
+    assert by_name == {"rangecheck.DecomposeHint": 27, "solver.InvZeroHint": 6, "bits.nBits": 2, "sw-grumpkin.decomposeScalar": 1,
+                       "sw-grumpkin.decompose": 1, "emulated.mulHint": 1, "logderivarg.countHint": 1, "hints.Randomize": 1,
+                       "cs.Bsb22CommitmentComputePlaceholder": 1}
+    # every term names an existing coefficient-table entry and wire; hint outputs are fresh internal wires, in order
+    assert all(wi < s.n_wires for row in s.rows for side in row for _, wi in side)
+    assert all(6190 <= h[4] < h[5] <= 12939 for h in s.hints) and [h[4] for h in s.hints] == sorted(h[4] for h in s.hints)
+    # the commitment: its 490 committed wires are the inputs of the placeholder hint, its value lands on one fresh wire
+    ci = c.meta["CommitmentInfo"].value[0]
+    bsb = [h for h in s.hints if h[2].endswith("Bsb22CommitmentComputePlaceholder")][0]
+    assert [t[0][1] for t in bsb[3][1:]] == ci["PrivateCommitted"] and bsb[5] - bsb[4] == 1
+    # the Grumpkin scalar is decomposed against the BN254 base field (4 x 64-bit limbs) with the curve's cube root of unity
+    dec = [h for h in s.hints if h[2].endswith("decomposeScalar")][0]
+    q = sum(t[0][0] << (64 * i) for i, t in enumerate(dec[3][9:13]))
+    assert q == 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47
+
+
+def test_reference_r1cs_accepts_the_acir_executor_witness(program, withdraw_kat):
+    """gnark's solver loop over the decoded reference system, fed with the secret wires the ACIR executor solves (the .ccs names
+    them __witness_<i>): every R1C row that can be evaluated without the three hints whose code is not available -- 6 176 rows
+    checked outright, 4 690 more define a wire -- holds, for the reference inputs; a changed input breaks rows.  This pins the
+    stream decoding, the coefficient table, the wire numbering and the executor against the reference's own constraint system."""
+    from spp import ccs, acir
+    from oracle import circuit as C
+    c = ccs.load_ccs(os.path.join(GOLDEN, "reference_withdraw.ccs"))
+    s = ccs.decode_system(c)
+    row = C.withdraw_inputs(withdraw_kat)
+    w = acir.execute(program, row)
+    secret = {"__witness_%d" % k: v for k, v in w.items()}
+    wires, st = ccs.solve_partial(s, c, row[:5], secret)
+    assert st["rows_unsatisfied"] == [] and st["rows_checked"] == 6176 and st["rows_solved"] == 4690 and st["rows_skipped"] == 1586
+    assert st["hints_run"] == 12 and st["wires_known"] == 11108
+    # skipped: the three unavailable hints and what consumes their outputs (the scalar's bits and range checks, and with them the
+    # lookup multiplicities and the commitment over all 490 committed wires)
+    skipped = {name for _, name in st["hints_skipped"]}
+    assert skipped >= set(ccs.UNSUPPORTED_HINTS) and "hints.Randomize" not in skipped and len(st["hints_skipped"]) == 29
+    # a witness that is not the executor's: one hash state flipped
+    bad = dict(secret)
+    k = sorted(w)[3000]
+    bad["__witness_%d" % k] = (w[k] + 1) % ccs.R
+    _, st3 = ccs.solve_partial(s, c, row[:5], bad)
+    assert st3["rows_unsatisfied"]
+    # public inputs are bound as well
+    _, st4 = ccs.solve_partial(s, c, [row[0] + 1] + row[1:5], secret)
+    assert st4["rows_unsatisfied"]
+
+
 def test_fixtures_equal_the_reference_files():
     ref = "/root/reference/noir_circuit/target"
     if not os.path.exists(ref):
