@@ -187,6 +187,8 @@ struct AssembleArgs {
   uint32_t P;
 };
 void launch_assemble(hipStream_t st, AssembleArgs a);
+void launch_spin(hipStream_t st, uint64_t ticks_100mhz, uint32_t* sink);   // one lane busy-waits (bounded); stream-concurrency probe
+void launch_touch(hipStream_t st, uint32_t* sink);
 // Ws[row][p] = s_p * W[row][p], Wr[row][p] = r_p * W[row][p] for rows < n_rows (r, s = rows row_r, row_s of W)
 void launch_scale_witness(hipStream_t st, const Fr* W, Fr* Ws, Fr* Wr, uint32_t n_rows, uint32_t row_r, uint32_t row_s, uint32_t P);
 

@@ -128,6 +128,18 @@ void launch_scale_witness(hipStream_t st, const Fr* W, Fr* Ws, Fr* Wr, uint32_t 
   const uint64_t total = (uint64_t)n_rows * P;
   hipLaunchKernelGGL(k_scale_witness, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, W, Ws, Wr, n_rows, row_r, row_s, P);
 }
+// stream-concurrency probe (spp_api.cpp, pick_concurrent_stream): one lane waits `ticks` of the 100 MHz wall clock
+__global__ void k_spin(uint64_t ticks, uint32_t* __restrict__ sink) {
+  const uint64_t t0 = wall_clock64();
+  uint32_t n = 0;
+  while (wall_clock64() - t0 < ticks) n++;
+  if (sink) *sink = n;
+}
+__global__ void k_touch(uint32_t* __restrict__ sink) {
+  if (sink) *sink = 1;
+}
+void launch_spin(hipStream_t st, uint64_t ticks, uint32_t* sink) { hipLaunchKernelGGL(k_spin, dim3(1), dim3(1), 0, st, ticks, sink); }
+void launch_touch(hipStream_t st, uint32_t* sink) { hipLaunchKernelGGL(k_touch, dim3(1), dim3(1), 0, st, sink); }
 void launch_assemble(hipStream_t st, AssembleArgs a) {
   uint32_t lanes = 2 * a.P;
   hipLaunchKernelGGL(k_assemble, dim3((lanes + 63) / 64), dim3(64), 0, st, a);

@@ -2,6 +2,7 @@
 // trusted setup.  Everything heavy runs on the GPU; the host parses containers, derives one-time constants and enqueues
 // kernels.  There is deliberately no CPU implementation of the hot path here.
 #include "spp_internal.hpp"
+#include <chrono>
 
 thread_local char g_spp_err[512] = "";
 extern "C" const char* spp_last_error(void) { return g_spp_err; }
@@ -502,6 +503,7 @@ extern "C" int spp_circuit_build_acir(const uint8_t* blob, size_t blob_len, int 
 // -----------------------------------------------------------------------------------------------------
 // context
 // -----------------------------------------------------------------------------------------------------
+static int pick_concurrent_stream(hipStream_t ref, hipStream_t* out);
 extern "C" int spp_init(int device, spp_ctx** out) {
   if (!out) return fail(SPP_ERR_BAD_INPUT, "out is NULL");
   int count = 0;
@@ -513,10 +515,41 @@ extern "C" int spp_init(int device, spp_ctx** out) {
   ctx->device = device;
   HIP_TRY(hipStreamCreate(&ctx->stream));
   HIP_TRY(hipStreamCreate(&ctx->pstream[0]));
-  HIP_TRY(hipStreamCreate(&ctx->pstream[1]));
+  if (int e = pick_concurrent_stream(ctx->pstream[0], &ctx->pstream[1])) return e;
   *out = ctx;
   return SPP_OK;
 }
+// A new stream that really runs beside `ref`.  HIP multiplexes the streams of one priority onto a few hardware queues in
+// creation order; two streams that share a queue execute in submission order, and which ones do depends on how many streams
+// the process (torch included) created before -- seen as run-to-run differences of 4 % on pipelined batches and 0.5 ms on a
+// single proof whose G2 sum ran in front of the matrix evaluation instead of beside it.  Probe: a one-lane kernel that waits
+// 2 ms on `ref`, a trivial kernel on the candidate; the candidate is kept if its kernel finishes while the other still waits.
+static int pick_concurrent_stream(hipStream_t ref, hipStream_t* out) {
+  static const bool probe = getenv("SPP_NO_STREAM_PROBE") == nullptr;
+  hipStream_t rejected[6];
+  int nrej = 0;
+  *out = nullptr;
+  for (int attempt = 0; attempt < 6 && probe; attempt++) {
+    hipStream_t cand;
+    HIP_TRY(hipStreamCreate(&cand));
+    HIP_TRY(hipStreamSynchronize(ref));
+    launch_spin(ref, 200000, nullptr);            // 2 ms of the 100 MHz wall clock
+    const auto t0 = std::chrono::steady_clock::now();
+    launch_touch(cand, nullptr);
+    HIP_TRY(hipStreamSynchronize(cand));
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    HIP_TRY(hipStreamSynchronize(ref));
+    if (ms < 1.0) {
+      *out = cand;
+      break;
+    }
+    rejected[nrej++] = cand;                      // keep it alive until the search ends: destroying it would free its queue slot
+  }
+  for (int i = 0; i < nrej; i++) hipStreamDestroy(rejected[i]);
+  if (!*out) HIP_TRY(hipStreamCreate(out));
+  return 0;
+}
+
 extern "C" void spp_free_ctx(spp_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
@@ -913,7 +946,7 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
     // the other batch or by the G2 side stream
     const bool serial = getenv("SPP_SERIAL") != nullptr;
     w.own_st = ctx->pstream[k];
-    HIP_TRY(hipStreamCreate(&w.own_st2));
+    if (int e = pick_concurrent_stream(w.own_st, &w.own_st2)) return e;
     {
       // Batches run the G2 sum on a side stream with a priority of its own.  Streams of one priority share a few hardware queues
       // round-robin; when st and st2 land on the same one the G2 sum runs in front of the matrix evaluation instead of beside it.
