@@ -34,7 +34,7 @@ def main():
             row["kernel_cycles"] = round(cyc)
             row["valu_issue_util"] = round(4.0 * avg["SQ_ACTIVE_INST_VALU"] / (cyc * 1024), 4)
             if "SQ_INSTS_VALU" in avg:
-                row["cycles_per_valu_wave_instruction"] = round(4.0 * avg["SQ_ACTIVE_INST_VALU"] / avg["SQ_INSTS_VALU"], 3)
+                row["cycles_per_valu_wave_instruction"] = round(4.0 * avg["SQ_ACTIVE_INST_VALU"] / avg["SQ_INSTS_VALU"], 3) if avg.get("SQ_INSTS_VALU") else None
             if "SQ_WAVE_CYCLES" in avg:
                 row["mean_resident_waves_per_simd"] = round(4.0 * avg["SQ_WAVE_CYCLES"] / (cyc * 1024), 3)
         doc[name] = row
