@@ -122,6 +122,13 @@ int spp_prove_batch(spp_circuit* c, size_t count, const uint8_t* inputs, const u
 int spp_prove_batch_device(spp_circuit* c, size_t count, const void* d_inputs, const void* d_rs, void* d_proofs, void* d_pws,
                            void* d_status);
 int spp_sync(spp_circuit* c);
+/* The value of the circuit's commitment challenge for `count` (partial) input rows: loads the rows, commits to the committed
+ * wires (BSB22 / Pedersen, the commitment basis of the proving key) and hashes the commitment to the field exactly as the prover
+ * does between its two solver phases; out = count x 32 B big-endian.  For systems whose witness is completed OUTSIDE the library --
+ * the reference's own gnark R1CS (noir_circuit/target/shielded_pool_verifier.ccs decoded by spp/ccs.py, every wire an input): the
+ * wires after the commitment (the lookup argument's) depend on this value, gnark's solver gets it from the
+ * Bsb22CommitmentComputePlaceholder hint (`sunspot prove`, client/proof.helper.ts:58-64).  Wires not known yet are passed as 0. */
+int spp_commitment_challenge(spp_circuit* c, size_t count, const uint8_t* inputs, uint8_t* challenges);
 /* per-stage device time of the last spp_prove_batch_device call, milliseconds:
  * [0] witness solve (+commitment), [1] matrix eval, [2] NTT/QAP, [3] MSM G1, [4] wait for the G2 MSM (it runs on a side
  * stream from the end of [0]), [5] assembly, [6] total;

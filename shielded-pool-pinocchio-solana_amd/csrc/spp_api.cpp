@@ -1193,6 +1193,39 @@ extern "C" int spp_prove_batch_device(spp_circuit* c, size_t count, const void* 
   return prove_on_device(c, w, (uint32_t)count, (const uint8_t*)d_inputs, (const uint8_t*)d_rs, (uint8_t*)d_proofs, (uint8_t*)d_pws,
                          (uint32_t*)d_status);
 }
+extern "C" int spp_commitment_challenge(spp_circuit* c, size_t count, const uint8_t* inputs, uint8_t* challenges) {
+  if (!c || !inputs || !challenges) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  if (count == 0) return SPP_OK;
+  if (count > 4096) return fail(SPP_ERR_BAD_INPUT, "at most 4096 rows per call");
+  if (c->CB.N == 0) return fail(SPP_ERR_BAD_INPUT, "the circuit has no commitment");
+  std::lock_guard<std::mutex> lk(c->ctx->mu);
+  HIP_TRY(hipSetDevice(c->ctx->device));
+  Workspace& w = c->ws[c->next_ws];
+  if (int e = ensure_workspace(c, w, count)) return e;
+  hipStream_t st = w.st;
+  const uint32_t P = (uint32_t)count;
+  const size_t nin = c->circ.n_inputs();
+  HIP_TRY(hipMemcpyAsync(w.d_inputs, inputs, nin * 32 * count, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(w.d_rs, 0, 64 * count, st));
+  launch_load_inputs(st, w.d_inputs, w.d_rs, w.W, (uint32_t)nin, c->circ.n_wires, P);
+  // whatever the program computes before the commitment (nothing for an all-inputs system), then commit and hash
+  for (const SolveStep& s : c->schedule) {
+    if (s.kind == SolveStep::COMMIT) break;
+    switch (s.kind) {
+      case SolveStep::SEQ: launch_solve(st, c->dc, w.W, w.scratch, s.a, s.b, P); break;
+      case SolveStep::BATCH_DIV: launch_batch_div(st, c->dc, w.W, w.scratch, s.a, s.b, P); break;
+      case SolveStep::COUNT8: launch_count8(st, c->dc, w.W, w.counters, s.a, s.b, s.c, P); break;
+      default: break;
+    }
+  }
+  run_msm(c, w, c->CB, w.CB, P, false);
+  launch_challenge(st, w.CB.out, w.W, c->circ.challenge_wire, P, w.commit_affine, w.d_status);
+  std::vector<Fr> out(count);
+  HIP_TRY(hipMemcpyAsync(out.data(), w.W + (size_t)c->circ.challenge_wire * P, sizeof(Fr) * count, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  for (size_t i = 0; i < count; i++) out[i].to_bytes_be(challenges + 32 * i);
+  return SPP_OK;
+}
 extern "C" int spp_sync(spp_circuit* c) {
   if (!c) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
   HIP_TRY(hipSetDevice(c->ctx->device));

@@ -323,7 +323,88 @@ def decode_system(c):
 # ---------------------------------------------------------------------------------------------------------------------
 # gnark's solver loop on the decoded system
 # ---------------------------------------------------------------------------------------------------------------------
-UNSUPPORTED_HINTS = ("emulated.mulHint", "sw-grumpkin.decompose", "sw-grumpkin.decomposeScalar")
+UNSUPPORTED_HINTS = ()
+
+# Grumpkin's group order is the BN254 base field modulus; LAMBDA is the eigenvalue of its endomorphism (a cube root of unity mod Q).
+Q_BASE = 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47
+GLV_BITS = 127
+GLV_LAMBDA = 0x59e26bcea0d48bacd4f263f1acdb5c4f5763473177fffffe
+
+
+def _limbs(v, n, bits):
+    return [(v >> (bits * i)) & ((1 << bits) - 1) for i in range(n)]
+
+
+def glv_split(s, lam, q=Q_BASE, bits=GLV_BITS):
+    """(s1, s2) with 0 <= s1, s2 < 2^bits and s1 - lam * s2 = s (mod q) -- what the rows after `sw-grumpkin.decomposeScalar` demand of
+    its outputs (s_limbs + lam * s2 - s1 = 0 mod q through emulated.mulHint, both halves recomposed from `bits` bits).  Sunspot's own
+    hint is not in the reference tree; ANY pair with these properties satisfies the system, so this one is found from scratch: a
+    reduced basis of the lattice {(x, y): x = lam * y mod q} by the extended Euclid on (q, lam), Babai rounding of (s, 0), then the
+    neighbouring lattice points until both coordinates are in range (the box holds 2^254 / q = 5.3 lattice points on average)."""
+    r0, r1, t0, t1 = q, lam % q, 0, 1
+    rows = []
+    while r1:
+        k = r0 // r1
+        r0, r1, t0, t1 = r1, r0 - k * r1, t1, t0 - k * t1
+        rows.append((r0, t0))                      # r0 = t0 * lam (mod q)
+    lim = 1 << (q.bit_length() // 2)
+    i = next(j for j, (r, _) in enumerate(rows) if r < lim)
+    v1, v2 = rows[i], rows[i + 1]                  # consecutive remainders: |det| = q, both vectors of norm ~ sqrt(q)
+    det = v1[0] * v2[1] - v2[0] * v1[1]
+    if det < 0:
+        v1, v2, det = v2, v1, -det
+    # (s, 0) = b1 v1 + b2 v2 over the rationals, rounded to the nearest integers
+    b1 = (2 * s * v2[1] + det) // (2 * det)
+    b2 = (-2 * s * v1[1] + det) // (2 * det)
+    for radius in range(0, 6):
+        for i1 in range(-radius, radius + 1):
+            for i2 in range(-radius, radius + 1):
+                if max(abs(i1), abs(i2)) != radius:
+                    continue
+                x = s - (b1 + i1) * v1[0] - (b2 + i2) * v2[0]
+                y = -(b1 + i1) * v1[1] - (b2 + i2) * v2[1]
+                if 0 <= x < 1 << bits and 0 <= y < 1 << bits:
+                    assert (x - lam * y - s) % q == 0
+                    return x, y
+    raise ValueError("no decomposition in range")
+
+
+def _emulated_mul_hint(ins, n_out):
+    """gnark std/math/emulated mulHint as this system calls it: inputs [limb bits, modulus limbs n, limbs of a, limbs of the
+    quotient, modulus limbs..., a limbs..., b limbs...]; outputs quotient limbs, remainder limbs (n), carry limbs.  The rows that
+    consume them (decoded from the .ccs) check  a(X) b(X) = k(X) p(X) + r(X) + (2^bits - X) c(X)  at a random X, so: k = a*b div p,
+    r = a*b mod p as limbs, and c by dividing the difference by (2^bits - X) coefficient by coefficient (field elements)."""
+    bits, n, na, nq = ins[0], ins[1], ins[2], ins[3]
+    p_l = ins[4:4 + n]
+    a_l = ins[4 + n:4 + n + na]
+    b_l = ins[4 + n + na:]
+    B = 1 << bits
+    val = lambda ls: sum(v << (bits * i) for i, v in enumerate(ls))
+    pv, av, bv = val(p_l), val(a_l), val(b_l)
+    quo, rem = divmod(av * bv, pv)
+    k_l, r_l = _limbs(quo, nq, bits), _limbs(rem, n, bits)
+    if quo >> (bits * nq):
+        raise ValueError("quotient does not fit")
+    ncarry = n_out - nq - n
+    d = [0] * (ncarry + 1)
+    for i, x in enumerate(a_l):
+        for j, y in enumerate(b_l):
+            d[i + j] += x * y
+    for i, x in enumerate(k_l):
+        for j, y in enumerate(p_l):
+            d[i + j] -= x * y
+    for i, x in enumerate(r_l):
+        d[i] -= x
+    carries, c = [], 0
+    for i in range(ncarry):                          # d_i = B c_i - c_{i-1}
+        num = d[i] + c
+        if num % B:
+            raise ValueError("carry %d is not integral" % i)
+        c = num // B
+        carries.append(c % R)
+    if d[ncarry] + c != 0:
+        raise ValueError("the product identity does not close")
+    return k_l + r_l + carries
 
 
 def _hint_outputs(name, ins, n_out, challenge):
@@ -337,8 +418,8 @@ def _hint_outputs(name, ins, n_out, challenge):
         return [(ins[2] >> (width * i)) & ((1 << width) - 1) for i in range(n_out)]
     if short == "solver.InvZeroHint":                       # 1/x, or 0 for 0
         return [pow(v, -1, R) if v else 0 for v in ins][:n_out]
-    if short == "logderivarg.countHint":                    # inputs: row width, table size, table rows, queries -> multiplicities
-        nb_vals, nb_table = ins[0], ins[1]
+    if short == "logderivarg.countHint":                    # inputs: table size, row width, table rows, queries -> multiplicities
+        nb_table, nb_vals = ins[0], ins[1]
         table = {}
         flat = ins[2:]
         for i in range(nb_table):
@@ -348,6 +429,15 @@ def _hint_outputs(name, ins, n_out, challenge):
         for i in range(len(q) // nb_vals):
             counts[table[tuple(q[i * nb_vals:(i + 1) * nb_vals])]] += 1
         return counts[:n_out]
+    if short == "sw-grumpkin.decompose":                    # the scalar as 64-bit limbs
+        return _limbs(ins[0], n_out, 64)
+    if short == "sw-grumpkin.decomposeScalar":              # inputs: six layout words, the scalar, limb count, limb bits, modulus limbs
+        nl, bits = ins[7], ins[8]
+        q = sum(v << (bits * i) for i, v in enumerate(ins[9:9 + nl]))
+        s1, s2 = glv_split(ins[6], GLV_LAMBDA, q)
+        return _limbs(s1, nl, bits) + _limbs(s2, nl, bits)
+    if short == "emulated.mulHint":
+        return _emulated_mul_hint(ins, n_out)
     if short == "hints.Randomize":                          # any value satisfies the rows that use it
         return [challenge] * n_out
     if short == "cs.Bsb22CommitmentComputePlaceholder":     # the commitment challenge: any value satisfies the rows
@@ -355,9 +445,12 @@ def _hint_outputs(name, ins, n_out, challenge):
     return None
 
 
-def solve_partial(system, c, public_inputs, secret_by_name, challenge=0x5EED):
+def solve_partial(system, c, public_inputs, secret_by_name, challenge=0x5EED, challenge_fn=None):
     """-> (wires list with None for unknown, stats dict).  public_inputs: the five values after the constant wire;
-    secret_by_name: {"__witness_<i>": value}."""
+    secret_by_name: {"__witness_<i>": value}.  challenge_fn(wires) -> the commitment challenge (what gnark's
+    Bsb22CommitmentComputePlaceholder hint returns: the hash of the Pedersen commitment to the committed wires, which only the
+    holder of the proving key can compute -- spp_commitment_challenge); without it the fixed `challenge` is used, which satisfies
+    the rows just as well but not a verifier."""
     w = [None] * system.n_wires
     w[0] = 1
     for i, v in enumerate(public_inputs):
@@ -392,7 +485,10 @@ def solve_partial(system, c, public_inputs, secret_by_name, challenge=0x5EED):
                         else:
                             s += cf * w[wi]
                     vals.append(s % R)
-                outs = _hint_outputs(name, vals, o1 - o0, challenge) if ok else None
+                if ok and challenge_fn is not None and name.endswith("Bsb22CommitmentComputePlaceholder"):
+                    outs = [challenge_fn(w) % R]
+                else:
+                    outs = _hint_outputs(name, vals, o1 - o0, challenge) if ok else None
                 if outs is None:
                     stats["hints_skipped"].append((k, name.rsplit("/", 1)[-1]))
                     continue
@@ -434,3 +530,65 @@ def solve_partial(system, c, public_inputs, secret_by_name, challenge=0x5EED):
             stats["rows_solved"] += 1
     stats["wires_known"] = sum(v is not None for v in w)
     return w, stats
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the decoded system as a circuit of this repository's prover
+# ---------------------------------------------------------------------------------------------------------------------
+SPPC_MAGIC, SPPC_VERSION = 0x43505053, 2
+CIRCUIT_CCS = 6
+OP_END, OP_COMMIT = 0, 9
+
+
+def challenge_wire(system):
+    return [h for h in system.hints if h[2].endswith("Bsb22CommitmentComputePlaceholder")][0][4]
+
+
+def to_sppc(system, c, path):
+    """Writes the reference's R1CS as an SPPC container (csrc/circuit.cpp) so that `spp setup` / `spp_prove_batch` -- and the
+    oracle -- take it like any other circuit: same rows, same wire numbering (constant, 5 public, 6 184 ACIR witnesses, 6 749
+    internal), same coefficient table, the same 490 committed wires and commitment wire.  Every wire after the public ones is
+    declared an INPUT and the solver program is the commitment step alone: the witness is completed on the host by gnark's own
+    solver loop (`reference_witness`), the library checks every row, commits, and proves."""
+    coef_index = {}
+    coeffs = []
+
+    def cid(v):
+        if v not in coef_index:
+            coef_index[v] = len(coeffs)
+            coeffs.append(v)
+        return coef_index[v]
+
+    def sparse(side):
+        rowptr, flat = [0], []
+        for row in system.rows:
+            for cf, wi in row[side]:
+                flat += [wi, cid(cf)]
+            rowptr.append(len(flat) // 2)
+        return struct.pack("<2I", len(system.rows), len(flat) // 2) + struct.pack("<%dI" % len(rowptr), *rowptr) + \
+            struct.pack("<%dI" % len(flat), *flat)
+
+    mats = [sparse(0), sparse(1), sparse(2), struct.pack("<3I", 0, 0, 0)]      # A, B, C, no hint rows
+    committed = c.meta["CommitmentInfo"].value[0]["PrivateCommitted"]
+    program = [OP_COMMIT, OP_END]
+    n_public = len(c.public)
+    n = len(system.rows)
+    domain_log = max(1, (n - 1).bit_length())
+    head = struct.pack("<13I", SPPC_MAGIC, SPPC_VERSION, CIRCUIT_CCS, n_public, system.n_wires - n_public, system.n_wires, n, domain_log,
+                       challenge_wire(system), len(coeffs), len(committed), len(program), 0)
+    body = b"".join(v.to_bytes(32, "little") for v in coeffs) + b"".join(mats) + \
+        struct.pack("<%dI" % len(committed), *committed) + struct.pack("<%dI" % len(program), *program)
+    with open(path, "wb") as f:
+        f.write(head + body)
+    return n
+
+
+def reference_witness(system, c, public_inputs, secret_by_name, challenge_of_row):
+    """The full assignment of the reference's system as the input row of the container `to_sppc` writes (wires 1 .. n-1).
+    challenge_of_row(row with unknown wires as 0) -> commitment challenge (CircuitHandle.commitment_challenge on the GPU)."""
+    def chal(w):
+        return challenge_of_row([0 if v is None else v for v in w[1:]])
+    wires, st = solve_partial(system, c, public_inputs, secret_by_name, challenge_fn=chal)
+    if st["rows_unsatisfied"] or st["rows_skipped"] or st["hints_skipped"]:
+        raise ValueError("the inputs do not satisfy the reference's constraint system: %r" % {k: v for k, v in st.items() if v})
+    return wires[1:]

@@ -60,6 +60,7 @@ def load_library():
     L.spp_last_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     L.spp_timings.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_float)]
     L.spp_msm_kernel_ms.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_float)]
+    L.spp_commitment_challenge.argtypes = [vp, ctypes.c_size_t, ctypes.c_char_p, vp]
     L.spp_set_serial.argtypes = [vp, i32]
     L.spp_prove_withdraw.argtypes = [vp, ctypes.POINTER(WithdrawInputs), cp, vp, vp]
     L.spp_verify.argtypes = [cp, sz, cp, sz, cp, sz, ctypes.POINTER(i32)]

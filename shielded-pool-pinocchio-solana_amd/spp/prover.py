@@ -157,6 +157,15 @@ class CircuitHandle:
         return ([proofs.raw[PROOF_LEN * i:PROOF_LEN * (i + 1)] for i in range(count)],
                 [pws.raw[self.pw_len * i:self.pw_len * (i + 1)] for i in range(count)], list(status))
 
+    def commitment_challenge(self, inputs):
+        """The commitment challenge the prover derives for each (possibly partial) input row: spp_commitment_challenge."""
+        count = len(inputs)
+        buf = b"".join(int(v).to_bytes(32, "big") for row in inputs for v in row)
+        assert len(buf) == count * self.n_inputs * 32
+        out = ctypes.create_string_buffer(32 * count)
+        check(self.L.spp_commitment_challenge(self.h, count, buf, ctypes.cast(out, ctypes.c_void_p)))
+        return [int.from_bytes(out.raw[32 * i:32 * i + 32], "big") for i in range(count)]
+
     def prove_batch_device(self, count, d_inputs, d_rs, d_proofs, d_pws, d_status):
         """All arguments are raw device pointers (ints), e.g. torch tensors' data_ptr()."""
         check(self.L.spp_prove_batch_device(self.h, count, d_inputs, d_rs, d_proofs, d_pws, d_status))

@@ -185,9 +185,9 @@ def test_ccs_streams_decode_to_the_whole_constraint_system():
 
 def test_reference_r1cs_accepts_the_acir_executor_witness(program, withdraw_kat):
     """gnark's solver loop over the decoded reference system, fed with the secret wires the ACIR executor solves (the .ccs names
-    them __witness_<i>): every R1C row that can be evaluated without the three hints whose code is not available -- 6 176 rows
-    checked outright, 4 690 more define a wire -- holds, for the reference inputs; a changed input breaks rows.  This pins the
-    stream decoding, the coefficient table, the wire numbering and the executor against the reference's own constraint system."""
+    them __witness_<i>): all 41 hint calls run, 6 458 rows are checked outright and 5 994 more define a wire -- all 12 452 rows hold
+    and all 12 939 wires are assigned; a changed witness or public input breaks rows.  This pins the stream decoding, the coefficient
+    table, the wire numbering, the hint restatements and the executor against the reference's own constraint system."""
     from spp import ccs, acir
     from oracle import circuit as C
     c = ccs.load_ccs(os.path.join(GOLDEN, "reference_withdraw.ccs"))
@@ -196,12 +196,11 @@ def test_reference_r1cs_accepts_the_acir_executor_witness(program, withdraw_kat)
     w = acir.execute(program, row)
     secret = {"__witness_%d" % k: v for k, v in w.items()}
     wires, st = ccs.solve_partial(s, c, row[:5], secret)
-    assert st["rows_unsatisfied"] == [] and st["rows_checked"] == 6176 and st["rows_solved"] == 4690 and st["rows_skipped"] == 1586
-    assert st["hints_run"] == 12 and st["wires_known"] == 11108
-    # skipped: the three unavailable hints and what consumes their outputs (the scalar's bits and range checks, and with them the
-    # lookup multiplicities and the commitment over all 490 committed wires)
-    skipped = {name for _, name in st["hints_skipped"]}
-    assert skipped >= set(ccs.UNSUPPORTED_HINTS) and "hints.Randomize" not in skipped and len(st["hints_skipped"]) == 29
+    assert st["rows_unsatisfied"] == [] and st["rows_checked"] == 6458 and st["rows_solved"] == 5994 and st["rows_skipped"] == 0
+    assert st["hints_run"] == 41 and st["hints_skipped"] == [] and st["wires_known"] == 12939 and None not in wires
+    # the lookup argument holds for whatever challenge the commitment hint returns
+    _, st2 = ccs.solve_partial(s, c, row[:5], secret, challenge=987654321)
+    assert st2["rows_unsatisfied"] == [] and st2["rows_checked"] == 6458
     # a witness that is not the executor's: one hash state flipped
     bad = dict(secret)
     k = sorted(w)[3000]
@@ -211,6 +210,119 @@ def test_reference_r1cs_accepts_the_acir_executor_witness(program, withdraw_kat)
     # public inputs are bound as well
     _, st4 = ccs.solve_partial(s, c, [row[0] + 1] + row[1:5], secret)
     assert st4["rows_unsatisfied"]
+
+
+def _reference_system(tmp):
+    from spp import ccs
+    c = ccs.load_ccs(os.path.join(GOLDEN, "reference_withdraw.ccs"))
+    s = ccs.decode_system(c)
+    sppc = os.path.join(str(tmp), "shielded_pool_verifier_ccs.sppc")
+    assert ccs.to_sppc(s, c, sppc) == 12452
+    return c, s, sppc
+
+
+def _fresh_note_inputs(seed):
+    """withdraw inputs of a note that is not the reference KAT (client/merkle.ts semantics from oracle/hashes.py)"""
+    import random
+    from oracle import hashes as H
+    rng = random.Random(seed)
+    tree = H.MerkleTree()
+    sk, amount, rnd = rng.randrange(1, 1 << 128), rng.randrange(1, 1 << 40), rng.randrange(1 << 250)
+    for _ in range(3):
+        tree.insert(rng.randrange(1 << 250))
+    owner = H.fixed_base_scalar_mul(sk)
+    idx = tree.insert(H.poseidon_hash4(owner[0], owner[1], amount, rnd))
+    tree.insert(rng.randrange(1 << 250))
+    return [tree.root(), H.poseidon_hash2(sk, idx), rng.randrange(1, 1 << 240), amount, H.poseidon_hash2(owner[0], owner[1]),
+            sk, owner[0], owner[1], rnd, idx] + tree.proof(idx)
+
+
+def test_reference_r1cs_is_proved_by_the_oracle(program, withdraw_kat, tmp_path):
+    """SURVEY 8f-1 on the CPU side: the reference's OWN gnark constraint system (decoded from its .ccs) goes through setup, the
+    witness is completed by gnark's solver loop with every one of its 41 hint calls (the three whose code is in neither tree --
+    Sunspot's Grumpkin scalar decomposition and gnark's emulated product -- restated from the rows that consume their outputs),
+    all 12 452 rows hold, the oracle proves and the pairing verifier accepts; the key has the reference's vk size (1 296 B: 7
+    public-side points).  A witness that breaks the statement is refused."""
+    from spp import ccs, acir
+    from oracle import circuit as C, native, groth16
+    c, s, sppc = _reference_system(tmp_path)
+    oc = C.Circuit(sppc)
+    assert (oc.n_public, oc.n_wires, oc.n_constraints, oc.domain_log, oc.challenge_wire, len(oc.committed)) == (6, 12939, 12452, 14, 12426, 490)
+    pk, vk = str(tmp_path / "ref.pk"), str(tmp_path / "ref.vk")
+    native.setup(sppc, b"\x07" * 32, pk, vk)
+    assert os.path.getsize(vk) == os.path.getsize(os.path.join(GOLDEN, "reference_withdraw.vk")) == 1296
+    pr = native.Prover(sppc, pk)
+    cw = ccs.challenge_wire(s)
+
+    def chal(partial_row):      # the oracle is the checker here: its solver runs the commitment step and shows the wire
+        return pr.prove(partial_row, 1, 2, want_wires=True)[3][cw]
+    for k, row in enumerate((C.withdraw_inputs(withdraw_kat), _fresh_note_inputs(5))):
+        w = acir.execute(program, row)
+        secret = {"__witness_%d" % i: v for i, v in w.items()}
+        wires, st = ccs.solve_partial(s, c, row[:5], secret, challenge_fn=lambda ws: chal([0 if v is None else v for v in ws[1:]]))
+        assert st["rows_unsatisfied"] == [] and st["rows_skipped"] == 0 and st["hints_run"] == 41 and st["wires_known"] == 12939
+        assert st["rows_checked"] + st["rows_solved"] == 12452
+        rc, proof, pw = pr.prove(wires[1:], 1000 + k, 2000 + k)
+        assert rc == 0 and pw == groth16.public_witness_bytes(row[:5])
+        assert groth16.verify(open(vk, "rb").read(), proof, pw)
+        bad = list(wires[1:])
+        bad[9000] = (bad[9000] + 1) % ccs.R
+        assert pr.prove(bad, 1, 2)[0] == 1
+    # the scalar decomposition: every scalar has a pair in range
+    import random
+    rng = random.Random(3)
+    for sc in [0, 1, ccs.R - 1, (1 << 128) - 1, 1 << 128] + [rng.randrange(ccs.R) for _ in range(300)]:
+        s1, s2 = ccs.glv_split(sc, ccs.GLV_LAMBDA)
+        assert 0 <= s1 < 1 << 127 and 0 <= s2 < 1 << 127 and (s1 - ccs.GLV_LAMBDA * s2 - sc) % ccs.Q_BASE == 0
+
+
+@pytest.mark.gpu
+def test_reference_r1cs_is_proved_on_the_gpu(program, withdraw_kat, tmp_path):
+    """The same on the product side: GPU setup bytes equal the oracle's, spp_commitment_challenge returns the challenge the oracle's
+    solver derives, the proofs of the reference KAT and of a fresh note are byte-identical to the oracle's under the same blinding,
+    the host and the batched GPU verifier accept them, a broken witness is refused in place."""
+    import spp
+    from spp import ccs, acir
+    from oracle import circuit as C, native, groth16
+    c, s, sppc = _reference_system(tmp_path)
+    pk, vk, opk, ovk = (str(tmp_path / n) for n in ("ref.pk", "ref.vk", "oref.pk", "oref.vk"))
+    ctx = spp.Context(0)
+    try:
+        ctx.setup(sppc, b"\x07" * 32, pk, vk)
+        native.setup(sppc, b"\x07" * 32, opk, ovk)
+        assert open(pk, "rb").read() == open(opk, "rb").read() and open(vk, "rb").read() == open(ovk, "rb").read()
+        h = ctx.load_circuit(sppc, pk, 6)
+        try:
+            assert h.n_inputs == 12938
+            orc = native.Prover(sppc, opk)
+            cw = ccs.challenge_wire(s)
+            rows, fulls = [C.withdraw_inputs(withdraw_kat), _fresh_note_inputs(8)], []
+            for row in rows:
+                w = acir.execute(program, row)
+                secret = {"__witness_%d" % i: v for i, v in w.items()}
+                seen = []
+
+                def chal(partial_row):
+                    got = h.commitment_challenge([partial_row])[0]
+                    seen.append((got, orc.prove(partial_row, 1, 2, want_wires=True)[3][cw]))
+                    return got
+                fulls.append(ccs.reference_witness(s, c, row[:5], secret, chal))
+                assert len(seen) == 1 and seen[0][0] == seen[0][1]
+            bad = list(fulls[0])
+            bad[7000] = (bad[7000] + 1) % ccs.R
+            rs = [(31, 57), (2 ** 200 + 5, 2 ** 199 + 9), (3, 4)]
+            proofs, pws, status = h.prove_batch(fulls + [bad], rs)
+            assert status[:2] == [0, 0] and status[2] != 0 and proofs[2] == bytes(388)
+            vkb = open(vk, "rb").read()
+            for i in range(2):
+                rc, proof, pw = orc.prove(fulls[i], rs[i][0], rs[i][1])
+                assert rc == 0 and proofs[i] == proof and pws[i] == pw == groth16.public_witness_bytes(rows[i][:5])
+                assert spp.verify(vkb, proofs[i], pws[i]) and groth16.verify(vkb, proofs[i], pws[i])
+            assert ctx.verify_batch(vkb, proofs[:2], pws[:2]) == [True, True]
+        finally:
+            h.close()
+    finally:
+        ctx.close()
 
 
 def test_fixtures_equal_the_reference_files():
