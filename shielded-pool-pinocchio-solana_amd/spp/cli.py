@@ -12,6 +12,11 @@ output-file naming (outputs land next to the circuit file, as sunspot writes the
     python -m spp.cli prove   target/<name>.json target/<name>.gz target/<name>.sppc target/<name>.pk
                               # sunspot's own argument order (acir, witness, constraint system, proving key;
                               # client/proof.helper.ts:58-64): the inputs are taken from the nargo witness file
+    python -m spp.cli compile target/<name>.ccs                                                  # the reference's OWN gnark R1CS -> <name>.sppc
+    python -m spp.cli setup   target/<name>.ccs [--seed HEX32]                                   # `sunspot setup <ccs>` -> <name>.pk, <name>.vk
+    python -m spp.cli prove   target/<name>.json target/<name>.gz target/<name>.ccs target/<name>.pk
+                              # `sunspot prove` on the files sunspot itself takes: gnark's solver loop (spp/ccs.py) completes the
+                              # witness of the .ccs from the nargo witness, the GPU checks every row, commits and proves
 
 Reference call sites: noir_circuit/prove_linux.sh:66-87, audit_circuit/prove_audit.sh:53-99,
 scripts/generate_audit.py:659-691, scripts/benchmark_all.py:646-690 (parses the `nbConstraints=` line).
@@ -71,6 +76,17 @@ def main(argv=None):
     x = sub.add_parser("execute"); x.add_argument("acir"); x.add_argument("toml"); x.add_argument("-o", "--out", default=None)
     v = sub.add_parser("verify"); v.add_argument("vk"); v.add_argument("proof"); v.add_argument("pw")
     a = ap.parse_args(argv)
+    if a.cmd == "compile" and a.circuit.endswith(".ccs"):
+        from . import ccs
+        c = ccs.load_ccs(a.circuit)
+        n = ccs.to_sppc(ccs.decode_system(c), c, a.out or os.path.splitext(a.circuit)[0] + ".sppc")
+        print("nbConstraints=%d" % n)
+        return 0
+    if a.cmd == "setup" and a.sppc.endswith(".ccs"):
+        from . import ccs
+        c = ccs.load_ccs(a.sppc)
+        a.sppc = os.path.splitext(a.sppc)[0] + ".sppc"
+        ccs.to_sppc(ccs.decode_system(c), c, a.sppc)
     if a.cmd == "compile":
         if a.circuit not in ("withdraw", "audit"):
             # `sunspot compile target/<name>.json` (prove_linux.sh:66-70): the reference's own compiled ACIR -> R1CS
@@ -136,6 +152,37 @@ def main(argv=None):
         if len(a.files) == 3:
             sppc, pk, toml = a.files
             _, row = input_vector(parse_prover_toml(open(toml).read()))
+        elif len(a.files) == 4 and a.files[2].endswith(".ccs"):
+            # the reference's own constraint system: every wire is an input of the container, the witness comes from gnark's
+            # solver loop over the decoded .ccs, fed with the nargo witness and the commitment challenge of THIS proving key
+            from . import acir, ccs
+            acir_path, gz, ccs_path, pk = a.files
+            c = ccs.load_ccs(ccs_path)
+            system = ccs.decode_system(c)
+            sppc = os.path.splitext(ccs_path)[0] + ".sppc"
+            if not os.path.exists(sppc):
+                ccs.to_sppc(system, c, sppc)
+            stack = acir.read_witness_stack(gz)
+            public = acir.abi_input_row(acir.load_program(acir_path), stack)[:len(c.public) - 1]
+            secret = {"__witness_%d" % k: v for k, v in stack.items()}
+            ctx = Context(a.device)
+            h = ctx.load_circuit(sppc, pk, a.window)
+            try:
+                row = ccs.reference_witness(system, c, public, secret, lambda partial: h.commitment_challenge([partial])[0])
+                proofs, pws, status = h.prove_batch([row])
+            except (ValueError, KeyError) as e:
+                print("spp prove: %s" % e, file=sys.stderr)
+                return 1
+            finally:
+                h.close()
+                ctx.close()
+            if status[0] != 0:
+                print("spp prove: inputs do not satisfy the circuit", file=sys.stderr)
+                return 1
+            base = os.path.splitext(ccs_path)[0]
+            open(base + ".proof", "wb").write(proofs[0])
+            open(base + ".pw", "wb").write(pws[0])
+            return 0
         elif len(a.files) == 4:
             from . import acir
             acir_path, gz, sppc, pk = a.files

@@ -372,3 +372,32 @@ def test_cli_prove_from_nargo_files_on_gpu(tmp_path, withdraw_kat, withdraw_arti
     pw = open(str(tmp_path / "shielded_pool_verifier.pw"), "rb").read()
     assert len(proof) == 388 and pw == groth16.public_witness_bytes(C.withdraw_inputs(withdraw_kat)[:5])
     assert spp.verify(open(withdraw_artifacts["vk"], "rb").read(), proof, pw)
+
+
+@pytest.mark.gpu
+def test_cli_on_the_files_sunspot_itself_takes(tmp_path, withdraw_kat):
+    """`sunspot setup <ccs>` and `sunspot prove <acir> <witness> <ccs> <pk>` (noir_circuit/prove_linux.sh:72-83, proof.helper.ts:58-64)
+    with the reference's own .json and .ccs and a nargo-style witness file: keys, proof and public witness land next to the .ccs."""
+    import shutil
+    import spp
+    from spp import cli, acir
+    from oracle import circuit as C, groth16
+    ccs_path = str(tmp_path / "shielded_pool_verifier.ccs")
+    shutil.copy(os.path.join(GOLDEN, "reference_withdraw.ccs"), ccs_path)
+    acir_path = os.path.join(GOLDEN, "reference_withdraw_acir.json")
+    gz = str(tmp_path / "shielded_pool_verifier.gz")
+    row = C.withdraw_inputs(withdraw_kat)
+    acir.write_witness_stack(gz, acir.execute(acir.load_program(acir_path), row))
+    assert cli.main(["setup", ccs_path, "--seed", "11" * 32]) == 0
+    base = str(tmp_path / "shielded_pool_verifier")
+    assert os.path.getsize(base + ".vk") == 1296
+    assert cli.main(["prove", acir_path, gz, ccs_path, base + ".pk", "--window", "6"]) == 0
+    proof, pw = open(base + ".proof", "rb").read(), open(base + ".pw", "rb").read()
+    assert len(proof) == 388 and pw == groth16.public_witness_bytes(row[:5])
+    assert cli.main(["verify", base + ".vk", base + ".proof", base + ".pw"]) == 0
+    assert groth16.verify(open(base + ".vk", "rb").read(), proof, pw)
+    # a witness of other inputs is refused
+    bad = acir.read_witness_stack(gz)
+    bad[sorted(bad)[2500]] = 1
+    acir.write_witness_stack(gz, bad)
+    assert cli.main(["prove", acir_path, gz, ccs_path, base + ".pk", "--window", "6"]) == 1
