@@ -35,6 +35,7 @@ struct DevCircuit {
   // constraints of a Poseidon S-box share B = the S-box input): run r covers rows run_start[r] .. run_start[r+1]-1
   const uint32_t* run_start;
   uint32_t n_runs;
+  uint32_t max_row_terms;   // longest row of A, B, C (small batches of circuits with long rows take the 16-lanes-per-row evaluation)
   // solver shortcuts per constraint: bit 0 = the B row is identical to the B row of constraint k - 1, bit 1 = the A row is
   // identical to the B row (a square).  A solver lane that has just evaluated row k - 1 reuses the value instead of walking
   // the same linear form again: the rows of a power map share their B side, and compiled (ACIR) circuits have long forms.

@@ -788,7 +788,9 @@ __global__ void __launch_bounds__(256) k_spmv_check_rows(DevCircuit dc, const Fr
   abc[2 * total + e] = c;
 }
 void launch_spmv_check(hipStream_t st, DevCircuit dc, const Fr* W, Fr* abc, uint32_t n, uint32_t P, uint32_t* status) {
-  if ((uint64_t)dc.n_runs * P < 65536) {
+  // circuits with long rows, up to 64 proofs: with 16 lanes per row the longest row is what a small batch waits for (audit: 0.3 ms +
+  // 33 us per proof against 4.4 ms for the run kernel's single lane on the 6 720-term row; measured equal near 128 proofs)
+  if ((uint64_t)dc.n_runs * P < 65536 || (P <= 64 && dc.max_row_terms > 1024)) {
     const uint64_t lanes = (uint64_t)n * P * SPMV_G;
     hipLaunchKernelGGL(k_spmv_check_rows, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, st, dc, W, abc, n, P, status);
     return;

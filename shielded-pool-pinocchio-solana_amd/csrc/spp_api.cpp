@@ -60,10 +60,16 @@ struct SolveStep {
 // batches up to this size are solved by one wave per proof (k_solve_coop); above it the wave-per-64-proofs solver has the
 // better throughput (a cooperative wave runs ~1/3 of the dependent instructions, but 64 times as many waves)
 static constexpr uint32_t COOP_MAX_BATCH = 1024;
-// Up to this batch size s*Ar and r*Bs1 are two more fixed-base sums (sets A and B1 over the witness scaled by s and r) instead of
+// Up to a batch size that depends on the circuit s*Ar and r*Bs1 are two more fixed-base sums (sets A and B1 over the witness scaled by s and r) instead of
 // 254 doublings on one lane each: 3 ms of a single proof's 9.  The sums cost a third of a proof's table additions, so a batch
 // keeps the per-lane multiplication (its latency is shared by the whole batch).
-static constexpr uint32_t SCALED_BLIND_MAX_BATCH = 16;
+// Measured (profiles/batch_size_sweep.py): the two extra sums cost ~15 us per withdraw proof and ~60 us per audit proof, the
+// per-lane multiplication 3.3 ms per batch whatever its size -- so the switch is on the number of scaled scalars, P * (N_A + N_B1).
+static constexpr uint64_t SCALED_BLIND_MAX_SCALARS = 1500000;
+static uint32_t scaled_blind_max_batch(uint32_t n_a, uint32_t n_b1) {
+  const uint64_t n = (uint64_t)n_a + n_b1;
+  return n ? (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(1024, SCALED_BLIND_MAX_SCALARS / n)) : 1;
+}
 struct spp_circuit {
   spp_ctx* ctx = nullptr;
   std::vector<SolveStep> schedule;
@@ -752,6 +758,10 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
     if ((e = own_upload(c, &d_runs, runs))) return e;
     c->dc.run_start = d_runs;
     c->dc.n_runs = n_runs;
+    uint32_t longest = 0;
+    for (const Sparse* m : {&circ.A, &circ.B, &circ.C})
+      for (uint32_t k = 0; k < circ.n_constraints; k++) longest = std::max(longest, m->rowptr[k + 1] - m->rowptr[k]);
+    c->dc.max_row_terms = longest;
     std::vector<uint8_t> flags(std::max<uint32_t>(circ.n_constraints, 1), 0);
     for (uint32_t k = 0; k < circ.n_constraints; k++) {
       if (k > 0 && same_b(k)) flags[k] |= 1;
@@ -1056,7 +1066,7 @@ static int ensure_workspace(spp_circuit* c, Workspace& w, size_t P) {
       (e = ws_set(w, &c->CS, &w.CS, P)))
     return e;
   {
-    const size_t Ps = std::min<size_t>(P, SCALED_BLIND_MAX_BATCH);
+    const size_t Ps = std::min<size_t>(P, scaled_blind_max_batch(c->A.N, c->B1.N));
     if ((e = ws_set(w, &c->A, &w.sA, Ps)) || (e = ws_set(w, &c->B1, &w.rB, Ps)) || (e = ws_alloc(w, &w.Ws, (size_t)c->n_rows * Ps)) ||
         (e = ws_alloc(w, &w.Wr, (size_t)c->n_rows * Ps)))
       return e;
@@ -1089,7 +1099,7 @@ static int prove_on_device(spp_circuit* c, Workspace& w, uint32_t P, const uint8
   const uint32_t n = c->n;
   w.msm_ev_used = 0;
   w.last_P = P;
-  const bool scaled_blind = P <= SCALED_BLIND_MAX_BATCH && !c->no_coop;
+  const bool scaled_blind = P <= scaled_blind_max_batch(c->A.N, c->B1.N) && !c->no_coop;
   HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(uint32_t) * P, st));
   hipEventRecord(w.ev[0], st);
   // 1. inputs, solver phase 1, commitment, challenge, solver phase 2
