@@ -59,7 +59,10 @@ struct SolveStep {
 };
 // batches up to this size are solved by one wave per proof (k_solve_coop); above it the wave-per-64-proofs solver has the
 // better throughput (a cooperative wave runs ~1/3 of the dependent instructions, but 64 times as many waves)
-static constexpr uint32_t COOP_MAX_BATCH = 1024;
+static const uint32_t COOP_MAX_BATCH = [] {   // SPP_COOP_MAX (experiment) overrides
+  const char* e = getenv("SPP_COOP_MAX");
+  return e ? (uint32_t)atoi(e) : 1024u;
+}();
 // Up to a batch size that depends on the circuit s*Ar and r*Bs1 are two more fixed-base sums (sets A and B1 over the witness scaled by s and r) instead of
 // 254 doublings on one lane each: 3 ms of a single proof's 9.  The sums cost a third of a proof's table additions, so a batch
 // keeps the per-lane multiplication (its latency is shared by the whole batch).
