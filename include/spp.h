@@ -243,6 +243,9 @@ int spp_msm_g2(spp_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_
 
 /* General-base Pippenger (16-bit signed windows, bucket sort + accumulate + reduce) for large n; same conventions. */
 int spp_msm_g1_pippenger(spp_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[64]);
+/* the same over G2 (bases and out 128 B, gnark raw X.A1 | X.A0 | Y.A1 | Y.A0): the digit / count / scatter kernels are shared,
+ * the bucket kernels run on the G2 accumulator of the table walk */
+int spp_msm_g2_pippenger(spp_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[128]);
 /* Synthetic, device-resident form of the same MSM (BASELINE.json configs[4]: n = 2^24): bases k_i*G and scalars from
  * an LCG of `seed`; scale_be (optional) multiplies every scalar (linearity checks). Mean ms over `iters` runs. */
 int spp_msm_g1_pippenger_bench(spp_ctx* ctx, size_t n, uint64_t seed, const uint8_t scale_be[32], int iters, uint8_t out[64],

@@ -170,6 +170,9 @@ uint32_t msm_slices_split(uint32_t N, uint32_t P, uint32_t Q);
 
 // ---- general-base Pippenger (kernels_pippenger.hip) ----
 size_t pippenger_workspace_bytes(uint32_t n);
+size_t pippenger_workspace_bytes_g2(uint32_t n);
+void launch_pippenger_g2(hipStream_t st, const G2Affine* bases, const Fr* scalars, uint32_t n, void* workspace, G2XYZZ** out_windows,
+                         hipEvent_t ev0, hipEvent_t ev1);
 uint32_t pippenger_windows();
 void launch_pippenger_g1(hipStream_t st, const G1Affine* bases, const Fr* scalars, uint32_t n, void* workspace, G1XYZZ** out_windows,
                          hipEvent_t ev0, hipEvent_t ev1);

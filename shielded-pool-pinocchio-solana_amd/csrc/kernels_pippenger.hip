@@ -146,10 +146,17 @@ __device__ __forceinline__ uint32_t pip_bucket_of(const uint32_t* __restrict__ o
   }
   return lo;
 }
-__global__ void __launch_bounds__(256) k_pip_segments(const G1Affine* __restrict__ bases, uint32_t n, uint32_t nseg,
+// bucket accumulator per coordinate field: the unsaturated 9x29-bit forms of f29.hpp (G1: XYZZ29, G2: XYZZ29G2)
+template <class F> struct PipAcc;
+template <> struct PipAcc<Fq> { using type = XYZZ29<FqParams>; };
+template <> struct PipAcc<Fq2> { using type = XYZZ29G2; };
+
+template <class F>
+__global__ void __launch_bounds__(256) k_pip_segments(const Affine<F>* __restrict__ bases, uint32_t n, uint32_t nseg,
                                                       const uint32_t* __restrict__ offs, const uint32_t* __restrict__ hist,
-                                                      const uint32_t* __restrict__ sorted, G1XYZZ* __restrict__ buckets,
-                                                      G1XYZZ* __restrict__ head, G1XYZZ* __restrict__ tail) {
+                                                      const uint32_t* __restrict__ sorted, XYZZ<F>* __restrict__ buckets,
+                                                      XYZZ<F>* __restrict__ head, XYZZ<F>* __restrict__ tail) {
+  using Acc = typename PipAcc<F>::type;
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= PIP_W * nseg) return;
   const uint32_t j = g / nseg, sg = g % nseg;
@@ -165,9 +172,9 @@ __global__ void __launch_bounds__(256) k_pip_segments(const G1Affine* __restrict
   uint32_t b = pip_bucket_of(o, pos);                      // non-empty: pos lies in [o[b], o[b] + h[b])
   uint32_t bend = o[b] + h[b];
   bool from_before = pos > o[b];
-  XYZZ29<FqParams> acc = XYZZ29<FqParams>::infinity();     // unsaturated 9x29-bit accumulator (f29.hpp), as in k_msm_fixed
+  Acc acc = Acc::infinity();     // unsaturated 9x29-bit accumulator (f29.hpp), as in k_msm_fixed
   auto flush = [&](bool continues_after) {
-    const G1XYZZ r = acc.to_xyzz();
+    const XYZZ<F> r = acc.to_xyzz();
     if (from_before) head[g] = r;
     else if (continues_after) tail[g] = r;
     else buckets[(size_t)j * PIP_B + b] = r;
@@ -175,17 +182,17 @@ __global__ void __launch_bounds__(256) k_pip_segments(const G1Affine* __restrict
   // software pipeline: the index and the (randomly placed, 64 B) base of entry k + 1 are requested before the ~2.3 K
   // instructions of the addition of entry k, so the HBM round trip of the gather hides behind arithmetic of the same lane
   uint32_t e = seg[pos];
-  G1Affine p = bases[e & 0x7fffffffu];
+  Affine<F> p = bases[e & 0x7fffffffu];
   for (uint32_t k = pos; k < end; k++) {
     const uint32_t e_cur = e;
-    const G1Affine p_cur = p;
+    const Affine<F> p_cur = p;
     if (k + 1 < end) {
       e = seg[k + 1];
       p = bases[e & 0x7fffffffu];
     }
     if (k == bend) {                                       // next non-empty bucket starts here
       flush(false);
-      acc = XYZZ29<FqParams>::infinity();
+      acc = Acc::infinity();
       from_before = false;
       b++;
       while (h[b] == 0) b++;
@@ -197,29 +204,31 @@ __global__ void __launch_bounds__(256) k_pip_segments(const G1Affine* __restrict
   flush(bend > end);
 }
 // lane per (window, bucket): empty buckets -> infinity; buckets spanning several segments -> tail[s0] + head[s0+1..s1]
+template <class F>
 __global__ void __launch_bounds__(256) k_pip_fixup(uint32_t nseg, const uint32_t* __restrict__ offs, const uint32_t* __restrict__ hist,
-                                                   G1XYZZ* __restrict__ buckets, const G1XYZZ* __restrict__ head,
-                                                   const G1XYZZ* __restrict__ tail) {
+                                                   XYZZ<F>* __restrict__ buckets, const XYZZ<F>* __restrict__ head,
+                                                   const XYZZ<F>* __restrict__ tail) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= PIP_W * PIP_B) return;
   const uint32_t j = g / PIP_B, cnt = hist[g];
   if (cnt == 0) {
-    buckets[g] = G1XYZZ::infinity();
+    buckets[g] = XYZZ<F>::infinity();
     return;
   }
   const uint32_t s0 = offs[g] / PIP_SEG, s1 = (offs[g] + cnt - 1) / PIP_SEG;
   if (s0 == s1) return;                                    // written directly by its segment lane
-  G1XYZZ acc = tail[(size_t)j * nseg + s0];
+  XYZZ<F> acc = tail[(size_t)j * nseg + s0];
   for (uint32_t s = s0 + 1; s <= s1; s++) acc.add(head[(size_t)j * nseg + s]);
   buckets[g] = acc;
 }
 
 // chunk c of window j: S = sum_b B_b, T = sum_b (b_local + 1) B_b  (running-sum trick from the top bucket down)
-__global__ void __launch_bounds__(64) k_pip_chunks(const G1XYZZ* __restrict__ buckets, G1XYZZ* __restrict__ S, G1XYZZ* __restrict__ T) {
+template <class F>
+__global__ void __launch_bounds__(64) k_pip_chunks(const XYZZ<F>* __restrict__ buckets, XYZZ<F>* __restrict__ S, XYZZ<F>* __restrict__ T) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= PIP_W * PIP_NCHUNK) return;
-  const G1XYZZ* b = buckets + (size_t)g * PIP_CHUNK;
-  G1XYZZ run = G1XYZZ::infinity(), tot = G1XYZZ::infinity();
+  const XYZZ<F>* b = buckets + (size_t)g * PIP_CHUNK;
+  XYZZ<F> run = XYZZ<F>::infinity(), tot = XYZZ<F>::infinity();
   for (int k = PIP_CHUNK - 1; k >= 0; k--) {
     run.add(b[k]);
     tot.add(run);
@@ -229,14 +238,15 @@ __global__ void __launch_bounds__(64) k_pip_chunks(const G1XYZZ* __restrict__ bu
 }
 
 // window sum = sum_c ( T_c + (64 c) * S_c ); one 64-lane block per window, 8 chunks per lane
-__global__ void __launch_bounds__(64) k_pip_windows(const G1XYZZ* __restrict__ S, const G1XYZZ* __restrict__ T, G1XYZZ* __restrict__ out) {
-  __shared__ G1XYZZ sh[64];
+template <class F>
+__global__ void __launch_bounds__(64) k_pip_windows(const XYZZ<F>* __restrict__ S, const XYZZ<F>* __restrict__ T, XYZZ<F>* __restrict__ out) {
+  __shared__ XYZZ<F> sh[64];
   const uint32_t j = blockIdx.x, t = threadIdx.x;
-  G1XYZZ acc = G1XYZZ::infinity();
+  XYZZ<F> acc = XYZZ<F>::infinity();
   for (uint32_t c = t; c < PIP_NCHUNK; c += 64) {
     acc.add(T[j * PIP_NCHUNK + c]);
     // (64 c) * S_c by double-and-add on the 15-bit multiplier
-    G1XYZZ s = S[j * PIP_NCHUNK + c], m = G1XYZZ::infinity();
+    XYZZ<F> s = S[j * PIP_NCHUNK + c], m = XYZZ<F>::infinity();
     uint32_t k = PIP_CHUNK * c;
     for (int bit = 14; bit >= 0; bit--) {
       m.dbl_inplace();
@@ -247,7 +257,7 @@ __global__ void __launch_bounds__(64) k_pip_windows(const G1XYZZ* __restrict__ S
   sh[t] = acc;
   __syncthreads();
   for (uint32_t w = 32; w > 0; w >>= 1) {
-    if (t < w) { G1XYZZ a = sh[t]; a.add(sh[t + w]); sh[t] = a; }
+    if (t < w) { XYZZ<F> a = sh[t]; a.add(sh[t + w]); sh[t] = a; }
     __syncthreads();
   }
   if (t == 0) out[j] = sh[0];
@@ -260,41 +270,54 @@ static uint32_t pip_ntiles(uint32_t n) { return n ? (n + PIP_TILE - 1) / PIP_TIL
 static size_t pip_words(uint32_t n) {
   return (size_t)2 * PIP_W * PIP_B + (size_t)PIP_W * pip_ntiles(n) * PIP_B + (size_t)PIP_W * n + ((size_t)PIP_W * n + 1) / 2;
 }
-size_t pippenger_workspace_bytes(uint32_t n) {
+template <class F>
+static size_t pip_ws_bytes(uint32_t n) {
   size_t pts = (size_t)PIP_W * PIP_B + 2 * (size_t)PIP_W * PIP_NCHUNK + PIP_W + 2 * (size_t)PIP_W * pip_nseg(n);
-  return ((pip_words(n) * 4 + 255) / 256) * 256 + pts * sizeof(G1XYZZ);
+  return ((pip_words(n) * 4 + 255) / 256) * 256 + pts * sizeof(XYZZ<F>);
 }
+size_t pippenger_workspace_bytes(uint32_t n) { return pip_ws_bytes<Fq>(n); }
+size_t pippenger_workspace_bytes_g2(uint32_t n) { return pip_ws_bytes<Fq2>(n); }
 uint32_t pippenger_windows() { return PIP_W; }
 
 // window sums land in out_windows[16] (device); ev0/ev1 (optional) bracket the bucket-accumulation kernel
-void launch_pippenger_g1(hipStream_t st, const G1Affine* bases, const Fr* scalars, uint32_t n, void* workspace, G1XYZZ** out_windows,
-                         hipEvent_t ev0, hipEvent_t ev1) {
+template <class F>
+static void launch_pippenger(hipStream_t st, const Affine<F>* bases, const Fr* scalars, uint32_t n, void* workspace, XYZZ<F>** out_windows,
+                             hipEvent_t ev0, hipEvent_t ev1) {
   const uint32_t ntiles = pip_ntiles(n);
   uint32_t* hist = (uint32_t*)workspace;
   uint32_t* offs = hist + PIP_W * PIP_B;
   uint32_t* hist_tile = offs + PIP_W * PIP_B;
   uint32_t* sorted = hist_tile + (size_t)PIP_W * ntiles * PIP_B;
   int16_t* digits = (int16_t*)(sorted + (size_t)PIP_W * n);
-  G1XYZZ* buckets = (G1XYZZ*)((char*)workspace + ((pip_words(n) * 4 + 255) / 256) * 256);
-  G1XYZZ* S = buckets + (size_t)PIP_W * PIP_B;
-  G1XYZZ* T = S + (size_t)PIP_W * PIP_NCHUNK;
-  G1XYZZ* out = T + (size_t)PIP_W * PIP_NCHUNK;
+  XYZZ<F>* buckets = (XYZZ<F>*)((char*)workspace + ((pip_words(n) * 4 + 255) / 256) * 256);
+  XYZZ<F>* S = buckets + (size_t)PIP_W * PIP_B;
+  XYZZ<F>* T = S + (size_t)PIP_W * PIP_NCHUNK;
+  XYZZ<F>* out = T + (size_t)PIP_W * PIP_NCHUNK;
   const uint32_t nseg = pip_nseg(n);
-  G1XYZZ* head = out + PIP_W;
-  G1XYZZ* tail = head + (size_t)PIP_W * nseg;
+  XYZZ<F>* head = out + PIP_W;
+  XYZZ<F>* tail = head + (size_t)PIP_W * nseg;
   if (n) hipLaunchKernelGGL(k_pip_digits, dim3((n + 255) / 256), dim3(256), 0, st, scalars, n, digits);
   hipLaunchKernelGGL(k_pip_count, dim3(PIP_W * ntiles), dim3(1024), 0, st, digits, n, ntiles, hist_tile);
   hipLaunchKernelGGL(k_pip_totals, dim3(PIP_W * PIP_B / 256), dim3(256), 0, st, ntiles, hist_tile, hist);
   hipLaunchKernelGGL(k_pip_scan, dim3(PIP_W), dim3(1024), 0, st, hist, offs);
   hipLaunchKernelGGL(k_pip_scatter, dim3(PIP_W * ntiles), dim3(1024), 0, st, digits, n, ntiles, offs, hist_tile, sorted);
   if (ev0) hipEventRecord(ev0, st);
-  hipLaunchKernelGGL(k_pip_segments, dim3((PIP_W * nseg + 255) / 256), dim3(256), 0, st, bases, n, nseg, offs, hist, sorted, buckets, head,
-                     tail);
+  hipLaunchKernelGGL(k_pip_segments<F>, dim3((PIP_W * nseg + 255) / 256), dim3(256), 0, st, bases, n, nseg, offs, hist, sorted, buckets,
+                     head, tail);
   if (ev1) hipEventRecord(ev1, st);
-  hipLaunchKernelGGL(k_pip_fixup, dim3(PIP_W * PIP_B / 256), dim3(256), 0, st, nseg, offs, hist, buckets, head, tail);
-  hipLaunchKernelGGL(k_pip_chunks, dim3(PIP_W * PIP_NCHUNK / 64), dim3(64), 0, st, buckets, S, T);
-  hipLaunchKernelGGL(k_pip_windows, dim3(PIP_W), dim3(64), 0, st, S, T, out);
+  hipLaunchKernelGGL(k_pip_fixup<F>, dim3(PIP_W * PIP_B / 256), dim3(256), 0, st, nseg, offs, hist, buckets, head, tail);
+  hipLaunchKernelGGL(k_pip_chunks<F>, dim3(PIP_W * PIP_NCHUNK / 64), dim3(64), 0, st, buckets, S, T);
+  hipLaunchKernelGGL(k_pip_windows<F>, dim3(PIP_W), dim3(64), 0, st, S, T, out);
   *out_windows = out;
+}
+void launch_pippenger_g1(hipStream_t st, const G1Affine* bases, const Fr* scalars, uint32_t n, void* workspace, G1XYZZ** out_windows,
+                         hipEvent_t ev0, hipEvent_t ev1) {
+  launch_pippenger<Fq>(st, bases, scalars, n, workspace, out_windows, ev0, ev1);
+}
+// the same over G2 (the variant VERDICT r1 item 8 asked for): only the point kernels differ
+void launch_pippenger_g2(hipStream_t st, const G2Affine* bases, const Fr* scalars, uint32_t n, void* workspace, G2XYZZ** out_windows,
+                         hipEvent_t ev0, hipEvent_t ev1) {
+  launch_pippenger<Fq2>(st, bases, scalars, n, workspace, out_windows, ev0, ev1);
 }
 
 }  // namespace spp

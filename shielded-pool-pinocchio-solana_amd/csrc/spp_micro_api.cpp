@@ -73,6 +73,37 @@ extern "C" int spp_msm_g1_pippenger(spp_ctx* ctx, const uint8_t* bases, const ui
   return SPP_OK;
 }
 
+extern "C" int spp_msm_g2_pippenger(spp_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[128]) {
+  if (!ctx || !out || (n && (!bases || !scalars))) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  if (n >= (1u << 31)) return fail(SPP_ERR_BAD_INPUT, "too many points");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  std::vector<G2Affine> pts(n);
+  std::vector<Fr> sc(n);
+  for (size_t i = 0; i < n; i++) {
+    pts[i] = g2_from_raw(bases + 128 * i);
+    sc[i] = Fr::from_bytes_be(scalars + 32 * i);
+  }
+  DevBuf dp, ds, dw;
+  UP(dp, pts.data(), n * sizeof(G2Affine));
+  UP(ds, sc.data(), n * sizeof(Fr));
+  HIP_TRY(dw.alloc(pippenger_workspace_bytes_g2((uint32_t)n)));
+  G2XYZZ* win = nullptr;
+  launch_pippenger_g2(st, dp.as<G2Affine>(), ds.as<Fr>(), (uint32_t)n, dw.p, &win, nullptr, nullptr);
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipGetLastError());
+  std::vector<G2XYZZ> w(pippenger_windows());
+  HIP_TRY(hipMemcpy(w.data(), win, sizeof(G2XYZZ) * w.size(), hipMemcpyDeviceToHost));
+  G2XYZZ r = G2XYZZ::infinity();
+  for (int j = (int)w.size() - 1; j >= 0; j--) {
+    for (int k = 0; k < 16; k++) r.dbl_inplace();
+    r.add(w[j]);
+  }
+  g2_to_raw(r.to_affine(), out);
+  return SPP_OK;
+}
+
 // Synthetic micro-benchmark, everything on the device: bases_i = k_i * G (k_i from a 64-bit LCG of `seed`), scalars
 // uniform 254-bit values from the same generator; runs `iters` MSMs, returns the result of the last one, the mean
 // wall time of one MSM and the mean duration of the bucket-accumulation kernel (HIP events).

@@ -92,6 +92,7 @@ def load_library():
     L.spp_msm_g1.argtypes = [vp, cp, cp, sz, i32, vp]
     L.spp_msm_g2.argtypes = [vp, cp, cp, sz, i32, vp]
     L.spp_msm_g1_pippenger.argtypes = [vp, cp, cp, sz, vp]
+    L.spp_msm_g2_pippenger.argtypes = [vp, cp, cp, sz, vp]
     L.spp_msm_g1_pippenger_bench.argtypes = [vp, sz, ctypes.c_uint64, cp, i32, vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     L.spp_msm_g1_pippenger_bench_dist.argtypes = [vp, sz, ctypes.c_uint64, ctypes.c_uint32, cp, i32, vp, ctypes.POINTER(ctypes.c_float),
                                                   ctypes.POINTER(ctypes.c_float)]

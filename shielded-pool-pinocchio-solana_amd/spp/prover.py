@@ -77,6 +77,12 @@ class Context:
         check(self.L.spp_msm_g1_pippenger(self.h, bases_bytes, sc, len(scalars), ctypes.cast(out, ctypes.c_void_p)))
         return out.raw
 
+    def msm_g2_pippenger(self, bases_bytes, scalars):
+        out = ctypes.create_string_buffer(128)
+        sc = b"".join(int(s).to_bytes(32, "big") for s in scalars)
+        check(self.L.spp_msm_g2_pippenger(self.h, bases_bytes, sc, len(scalars), ctypes.cast(out, ctypes.c_void_p)))
+        return out.raw
+
     def pairing_check(self, pairs):
         """prod e(P, Q) == 1 on the GPU with the batched verifier's device pairing code (spp_pairing_check)."""
         ok = ctypes.c_int(0)

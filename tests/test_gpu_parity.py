@@ -95,6 +95,41 @@ def test_msm_g2_matches_oracle(ctx):
     assert got == out.raw
 
 
+def test_pippenger_g2_matches_oracle(ctx):
+    """The general-base Pippenger over G2 (shared digit / sort kernels, bucket kernels on the G2 accumulator) against the oracle's
+    MSM: random twist points with the scalar edge cases, repeated and cancelling bases inside one bucket, the empty sum, and
+    linearity at a size the oracle does not need to see (MSM(k s) = k MSM(s))."""
+    from oracle import bn254 as B, native
+    import ctypes
+    rng = random.Random(23)
+    pts = []
+    p = B.G2_GEN
+    for i in range(90):
+        p = B.g2_add(p, B.g2_mul(B.G2_GEN, rng.randrange(1, 1 << 64)))
+        pts.append(p)
+    bases = b"".join(B.g2_to_bytes(q) for q in pts)
+
+    def oracle(bb, sc):
+        out = ctypes.create_string_buffer(128)
+        native.lib().orc_msm_g2(bb, b"".join(s.to_bytes(32, "big") for s in sc), len(sc), ctypes.cast(out, ctypes.c_void_p))
+        return out.raw
+    for n in (0, 1, 7, 90):
+        sc = [rng.randrange(B.R) for _ in range(n)]
+        if n >= 7:
+            sc[0], sc[1], sc[2], sc[3], sc[4], sc[5] = 0, 1, B.R - 1, (B.R - 1) // 2, (B.R + 1) // 2, 255
+        assert ctx.msm_g2_pippenger(bases[:128 * n], sc) == oracle(bases[:128 * n], sc), n
+    g = B.g2_mul(B.G2_GEN, 0x77)
+    mix = b"".join(B.g2_to_bytes(g if i % 3 else B.g2_neg(g)) for i in range(200))
+    assert ctx.msm_g2_pippenger(mix, [5] * 200) == oracle(mix, [5] * 200)
+    # linearity on 3000 points (bases repeat, scalars do not)
+    big = bases * 34
+    sc = [rng.randrange(B.R) for _ in range(len(big) // 128)]
+    k = rng.randrange(1, B.R)
+    a = ctx.msm_g2_pippenger(big, sc)
+    b = ctx.msm_g2_pippenger(big, [s * k % B.R for s in sc])
+    assert b == B.g2_to_bytes(B.g2_mul(B.g2_from_bytes(a), k))
+
+
 def test_msm_g1_repeated_and_cancelling_bases(ctx):
     """Many copies of one base (and of its negative) with equal scalars: inside a lane the accumulator meets the very
     point it holds (doubling path of XYZZ29::madd) or its negative (cancellation to infinity and restart)."""
