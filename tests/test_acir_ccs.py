@@ -212,6 +212,33 @@ def test_reference_r1cs_accepts_the_acir_executor_witness(program, withdraw_kat)
     assert st4["rows_unsatisfied"]
 
 
+def test_reference_r1cs_binds_only_the_low_half_of_the_grumpkin_scalar(program):
+    """A property of the reference's gnark system that the decoding brings out: its Grumpkin multiplication is fed with the LOW
+    128-bit limb of the secret key only (the decomposition hints and the emulated product read wire 28 = __witness_27; the ACIR
+    MultiScalarMul takes (witness 27, witness 34) = (lo, hi)).  For a key >= 2^128 the ACIR program -- and this repository's own
+    R1CS -- derive the public key of the whole scalar, and the two rows of the gnark system that compare its result with the ACIR
+    outputs (1074, 1075) cannot hold; keys below 2^128 (what client/prover-params.toml uses: 127 bits) are unaffected."""
+    from spp import ccs, acir
+    c = ccs.load_ccs(os.path.join(GOLDEN, "reference_withdraw.ccs"))
+    s = ccs.decode_system(c)
+    msm = [op for op in program.main.opcodes if op[0] == "MultiScalarMul"][0]
+    assert msm[2] == [("witness", 27), ("witness", 34)] and c.secret[28 - 6] == "__witness_27"
+    dec = [h for h in s.hints if h[2].endswith("decomposeScalar")][0]
+    assert dec[3][6] == [(1, 28)]
+    from oracle import hashes as H
+    import random
+    rng = random.Random(9)
+    for sk, ok in ((rng.randrange(1 << 127, 1 << 128), True), ((1 << 128) + 5, False), (rng.randrange(1 << 250, 1 << 253), False)):
+        tree = H.MerkleTree()
+        owner = H.fixed_base_scalar_mul(sk)
+        amount, rnd = 7, rng.randrange(1 << 250)
+        idx = tree.insert(H.poseidon_hash4(owner[0], owner[1], amount, rnd))
+        row = [tree.root(), H.poseidon_hash2(sk, idx), 1, amount, H.poseidon_hash2(owner[0], owner[1]), sk, owner[0], owner[1], rnd, idx] + tree.proof(idx)
+        w = acir.execute(program, row)                       # the ACIR program accepts all three
+        _, st = ccs.solve_partial(s, c, row[:5], {"__witness_%d" % k: v for k, v in w.items()})
+        assert st["rows_unsatisfied"] == ([] if ok else [1074, 1075]), sk.bit_length()
+
+
 def _reference_system(tmp):
     from spp import ccs
     c = ccs.load_ccs(os.path.join(GOLDEN, "reference_withdraw.ccs"))
