@@ -58,6 +58,7 @@ def parse_args(argv=None):
     ap.add_argument("--window", type=int, default=int(os.environ.get("SPP_WINDOW", "0")), help="MSM window bits; 0 = auto (largest tables within the HBM budget)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline circuit only (profiling runs)")
+    ap.add_argument("--ccs-leg-only", action="store_true", help="diagnostic: only the leg that proves the reference's own gnark R1CS")
     ap.add_argument("--no-single", action="store_true", help="skip the single-proof latency leg (keeps profiler per-kernel averages clean)")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the host-buffer (PCIe-inclusive) leg: its chunks overlap on two workspaces and would "
                                                                 "stretch a profiler's per-kernel averages")
@@ -510,6 +511,78 @@ def main():
         return out
 
     strong = args.mode == "strong"
+    def reference_r1cs_leg(B=64, steps=10, warmup=3):
+        """the reference's OWN gnark constraint system (tests/golden/reference_withdraw.ccs = noir_circuit/target/
+        shielded_pool_verifier.ccs) set up and proved on the GPU.  Its witness is completed on the host by gnark's solver loop
+        (spp/ccs.py; a process pool here), the commitment challenge comes from spp_commitment_challenge; the timed region is the GPU
+        part, rows resident in HBM, as for every other leg.  B distinct notes."""
+        import multiprocessing as mp
+        from spp import ccs
+        golden = os.path.join(ROOT, "tests", "golden")
+        ccs_path, acir_path = os.path.join(golden, "reference_withdraw.ccs"), os.path.join(golden, "reference_withdraw_acir.json")
+        tmp = tempfile.mkdtemp(prefix="spp_bench_ccs_")
+        sppc, pkp, vkp = (os.path.join(tmp, "c." + e) for e in ("sppc", "pk", "vk"))
+        c = ccs.load_ccs(ccs_path)
+        system = ccs.decode_system(c)
+        n_rows = ccs.to_sppc(system, c, sppc)
+        ctx = spp.Context(local_rank)
+        ctx.setup(sppc, b"\x2a" * 32, pkp, vkp)
+        t0 = time.time()
+        h = ctx.load_circuit(sppc, pkp, args.window)
+        load_s = time.time() - t0
+        notes = workload.withdraw_rows(ctx, B, seed=91)               # distinct notes of one tree; keys below 2^128
+        rows = [workload.row_ints(notes, 26, i) for i in range(B)]
+        t0 = time.time()
+        with mp.get_context("spawn").Pool(min(16, os.cpu_count() or 1)) as pool:
+            first = pool.map(ccs.complete_witness_worker, [(ccs_path, acir_path, r, None) for r in rows])
+            chal = h.commitment_challenge(b"".join(first))
+            full = pool.map(ccs.complete_witness_worker, [(ccs_path, acir_path, r, ch) for r, ch in zip(rows, chal)])
+        witness_s = time.time() - t0
+        inp = torch.frombuffer(bytearray(b"".join(full)), dtype=torch.uint8).to(dev)
+        import random as _r
+        rng = _r.Random(4)
+        R_ = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+        rs = torch.frombuffer(bytearray(b"".join(rng.randrange(R_).to_bytes(32, "big") + rng.randrange(R_).to_bytes(32, "big") for _ in range(B))),
+                              dtype=torch.uint8).to(dev)
+        outs = [(torch.zeros(388 * B, dtype=torch.uint8, device=dev), torch.zeros(h.pw_len * B, dtype=torch.uint8, device=dev),
+                 torch.zeros(B, dtype=torch.int32, device=dev)) for _ in range(2)]
+
+        def step(k):
+            pr, pw, st = outs[k & 1]
+            h.prove_batch_device(B, inp.data_ptr(), rs.data_ptr(), pr.data_ptr(), pw.data_ptr(), st.data_ptr())
+        for k in range(warmup):
+            step(k)
+        h.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(warmup, warmup + steps):
+            step(k)
+        h.sync(); torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        pr, pw, st = outs[(warmup + steps - 1) & 1]
+        assert int(st.abs().sum().item()) == 0
+        pb, wb = pr.cpu().numpy().tobytes(), pw.cpu().numpy().tobytes()
+        vkb = open(vkp, "rb").read()
+        assert all(ctx.verify_batch(vkb, [pb[388 * i:388 * (i + 1)] for i in range(B)], [wb[h.pw_len * i:h.pw_len * (i + 1)] for i in range(B)]))
+        assert spp.verify(vkb, pb[:388], wb[:h.pw_len])
+        lat = []
+        for _ in range(8):
+            torch.cuda.synchronize(); tl = time.perf_counter()
+            h.prove_batch_device(1, inp.data_ptr(), rs.data_ptr(), pr.data_ptr(), pw.data_ptr(), st.data_ptr()); h.sync()
+            lat.append((time.perf_counter() - tl) * 1e3)
+        res = {"value": round(B * steps / elapsed, 1), "unit": "proofs/s", "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "warmup": warmup,
+               "config": {"workload": "the reference's own gnark R1CS (noir_circuit/target/shielded_pool_verifier.ccs decoded by spp/ccs.py: 12 452 rows, "
+                                      "41 hint calls, 657 levels), batch of %d distinct notes; witnesses completed on the host by gnark's solver loop, "
+                                      "rows resident in HBM when the clock starts" % B,
+                          "n_constraints": n_rows, "n_wires": system.n_wires, "domain": 1 << 14, "batch_per_gpu": B, "n_distinct_witnesses": len(set(full)),
+                          "host_witness_completion_s": round(witness_s, 1), "load_s": round(load_s, 2),
+                          "verified": "all %d proofs of the last batch by spp_verify_batch, one by spp_verify" % B},
+               "single_proof_latency_ms": round(sorted(lat[2:])[len(lat[2:]) // 2], 3)}
+        h.close(); ctx.close()
+        return res
+
+    if args.ccs_leg_only:
+        print(json.dumps({"withdraw_reference_gnark_r1cs": reference_r1cs_leg()}), flush=True)
+        return
     B0 = args.batch or DEFAULT_BATCH[args.circuit]
     main_res = run_circuit(args.circuit, B0, args.steps, args.warmup, not args.no_cpu_baseline and world == 1, args.total if strong else 0)
     extras = {}
@@ -521,6 +594,7 @@ def main():
         extras["withdraw_at_reference_r1cs_size"] = run_circuit("withdraw_refshape", DEFAULT_BATCH["withdraw_refshape"], 10, 3, False)
         extras["withdraw_depth20_variant"] = run_circuit("withdraw_depth20", DEFAULT_BATCH["withdraw_depth20"], 10, 3, False)
         extras["withdraw_compiled_from_reference_acir"] = run_circuit("withdraw_acir", DEFAULT_BATCH["withdraw_acir"], 10, 3, False)
+        extras["withdraw_reference_gnark_r1cs"] = reference_r1cs_leg()
         ctx = spp.Context(local_rank)
         extras["rlwe_witness_2p16"] = rlwe_leg(ctx, dev, rlwe_pk)
         extras["msm_g1_2p24"] = pippenger_leg(ctx)

@@ -324,6 +324,7 @@ def decode_system(c):
 # gnark's solver loop on the decoded system
 # ---------------------------------------------------------------------------------------------------------------------
 UNSUPPORTED_HINTS = ()
+RANDOMIZER = 0x5EED        # what hints.Randomize returns here (gnark draws it at random)
 
 # Grumpkin's group order is the BN254 base field modulus; LAMBDA is the eigenvalue of its endomorphism (a cube root of unity mod Q).
 Q_BASE = 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47
@@ -438,8 +439,8 @@ def _hint_outputs(name, ins, n_out, challenge):
         return _limbs(s1, nl, bits) + _limbs(s2, nl, bits)
     if short == "emulated.mulHint":
         return _emulated_mul_hint(ins, n_out)
-    if short == "hints.Randomize":                          # any value satisfies the rows that use it
-        return [challenge] * n_out
+    if short == "hints.Randomize":                          # any value satisfies the rows that use it; its wire is COMMITTED, so it
+        return [RANDOMIZER] * n_out                         # must not move with the challenge
     if short == "cs.Bsb22CommitmentComputePlaceholder":     # the commitment challenge: any value satisfies the rows
         return [challenge] * n_out
     return None
@@ -592,3 +593,25 @@ def reference_witness(system, c, public_inputs, secret_by_name, challenge_of_row
     if st["rows_unsatisfied"] or st["rows_skipped"] or st["hints_skipped"]:
         raise ValueError("the inputs do not satisfy the reference's constraint system: %r" % {k: v for k, v in st.items() if v})
     return wires[1:]
+
+
+_WORKER_CACHE = {}
+
+
+def complete_witness_worker(args):
+    """Process-pool worker (bench.py, batch drivers): (ccs path, acir path, input row, challenge | None) -> the witness row of the
+    container `to_sppc` writes, 32 B big-endian per wire.  challenge None: a placeholder is used -- the committed wires, hence the
+    commitment, do not depend on it -- and the caller repeats the call with the value spp_commitment_challenge returns."""
+    ccs_path, acir_path, row, challenge = args
+    key = (ccs_path, acir_path)
+    if key not in _WORKER_CACHE:
+        from . import acir
+        c = load_ccs(ccs_path)
+        _WORKER_CACHE[key] = (c, decode_system(c), acir.load_program(acir_path), acir)
+    c, system, program, acir = _WORKER_CACHE[key]
+    w = acir.execute(program, row)
+    secret = {"__witness_%d" % k: v for k, v in w.items()}
+    wires, st = solve_partial(system, c, row[:len(c.public) - 1], secret, challenge=0x5EED if challenge is None else challenge)
+    if st["rows_unsatisfied"] or st["rows_skipped"] or st["hints_skipped"]:
+        raise ValueError("the inputs do not satisfy the reference's constraint system")
+    return b"".join(v.to_bytes(32, "big") for v in wires[1:])

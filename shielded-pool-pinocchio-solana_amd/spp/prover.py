@@ -165,8 +165,12 @@ class CircuitHandle:
 
     def commitment_challenge(self, inputs):
         """The commitment challenge the prover derives for each (possibly partial) input row: spp_commitment_challenge."""
-        count = len(inputs)
-        buf = b"".join(int(v).to_bytes(32, "big") for row in inputs for v in row)
+        if isinstance(inputs, (bytes, bytearray)):      # rows already serialised: n_inputs x 32 B big-endian each
+            buf = bytes(inputs)
+            count = len(buf) // (self.n_inputs * 32)
+        else:
+            count = len(inputs)
+            buf = b"".join(int(v).to_bytes(32, "big") for row in inputs for v in row)
         assert len(buf) == count * self.n_inputs * 32
         out = ctypes.create_string_buffer(32 * count)
         check(self.L.spp_commitment_challenge(self.h, count, buf, ctypes.cast(out, ctypes.c_void_p)))
