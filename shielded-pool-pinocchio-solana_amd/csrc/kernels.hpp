@@ -108,13 +108,19 @@ void launch_load_inputs(hipStream_t st, const uint8_t* d_inputs_be, const uint8_
 static constexpr uint32_t SOLVE_SCRATCH_MIN_ROWS = 324;
 void launch_solve(hipStream_t st, DevCircuit dc, Fr* W, Fr* scratch, uint32_t pc_begin, uint32_t pc_end, uint32_t P);
 // cooperative solver for small batches (one wave per proof; kernels_solve.hip): items = (kind, a, b) triples
-enum : uint32_t { COOP_SEQ = 0, COOP_PAR = 1, COOP_LEVELS = 2, COOP_POSEIDON = 3, COOP_POSEIDON2 = 4, COOP_GRUMPKIN = 5 };
+enum : uint32_t { COOP_SEQ = 0, COOP_PAR = 1, COOP_LEVELS = 2, COOP_POSEIDON = 3, COOP_POSEIDON2 = 4, COOP_GRUMPKIN = 5, COOP_LEVEL_STREAM = 6 };
 struct DevCoop {
   const uint32_t* items;      // 3 words per item
   const uint32_t* par;        // COOP_PAR: (pc_begin, pc_end) pairs of independent instructions
   const uint32_t* lvl_ptr;    // COOP_LEVELS: rows lvl_rows[lvl_ptr[l] .. lvl_ptr[l+1]) form dependency level l
   const uint32_t* lvl_rows;
+  // COOP_LEVEL_STREAM (a = first chunk, b = chunks): the same levels flattened into self-contained records, in chunks of
+  // COOP_CHUNK words that the wave stages through LDS one ahead.  Level: [rows n | lanes per row << 24 | some A form << 29 | some C rest << 30][words in the level][offset of row 0..n-1]
+  // then per row [output wire][terms of A | bit 31: A = B][terms of B][terms of C without the output][(wire, coefficient word) ...];
+  // 0xffffffff instead of n: the rest of the chunk is padding.  No level crosses a chunk boundary.
+  const uint32_t* lvl_stream;
 };
+static constexpr uint32_t COOP_CHUNK = 1024;
 // independent item ranges of one stretch: track t (blockIdx.y) runs items [begin[t], end[t]); only track 0 may use `scratch`
 static constexpr uint32_t COOP_TRACKS = 4;
 struct CoopTracks { uint32_t n; uint32_t begin[COOP_TRACKS], end[COOP_TRACKS]; };

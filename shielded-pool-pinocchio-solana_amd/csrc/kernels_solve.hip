@@ -552,6 +552,7 @@ __device__ __forceinline__ void solve_c_row(const DevCircuit& dc, Fr* __restrict
 
 __global__ void __launch_bounds__(64) k_solve_coop(DevCircuit dc, DevCoop co, Fr* __restrict__ W, Fr* __restrict__ scratch, CoopTracks tracks,
                                                    uint32_t P) {
+  __shared__ uint32_t lvl_buf[2][COOP_CHUNK];
   const uint32_t p = blockIdx.x, lane = threadIdx.x;
   uint32_t item = tracks.begin[blockIdx.y];
   const uint32_t item_end = tracks.end[blockIdx.y];
@@ -601,6 +602,64 @@ __global__ void __launch_bounds__(64) k_solve_coop(DevCircuit dc, DevCoop co, Fr
           __syncthreads();
         }
         break;
+      case COOP_LEVEL_STREAM: {
+        // A level of a compiled program is one to three short rows, and 4 800 levels follow one another: what a level costs is
+        // the chain of dependent loads (level table -> row list -> row pointers -> term indices -> witness).  Here everything but
+        // the witness comes out of LDS, staged one chunk ahead.
+        const uint32_t* __restrict__ stream = co.lvl_stream + (size_t)a * COOP_CHUNK;
+        for (uint32_t i = lane; i < COOP_CHUNK; i += 64) lvl_buf[0][i] = stream[i];
+        __syncthreads();
+        for (uint32_t ch = 0; ch < b; ch++) {
+          uint32_t pre[COOP_CHUNK / 64];
+          const bool more = ch + 1 < b;
+          if (more) {
+            SPP_UNROLL for (uint32_t j = 0; j < COOP_CHUNK / 64; j++) pre[j] = stream[(size_t)(ch + 1) * COOP_CHUNK + lane + 64 * j];
+          }
+          const uint32_t* sb = lvl_buf[ch & 1];
+          uint32_t pos = 0;
+          while (pos < COOP_CHUNK) {
+            const uint32_t nr = sb[pos] & 0xffffffu;
+            if (sb[pos] == 0xffffffffu) break;
+            const uint32_t G = (sb[pos] >> 24) & 31u;   // lanes per row, chosen by the host from the longest form of the level
+            const uint32_t per_pass = 64 / G, sub = lane % G;
+            for (uint32_t r = 0; r < nr; r += per_pass) {
+              const uint32_t mine = r + lane / G;
+              const bool live = mine < nr;
+              const uint32_t base = pos + (live ? sb[pos + 2 + mine] : 2 + nr);
+              const uint32_t out = live ? sb[base] : 0, na_w = live ? sb[base + 1] : 0;
+              const uint32_t nA = na_w & 0x7fffffffu, nB = live ? sb[base + 2] : 0, nC = live ? sb[base + 3] : 0;
+              auto dot = [&](uint32_t start, uint32_t n) {
+                Fr acc = Fr::zero();
+                for (uint32_t t = sub; t < n; t += G) {
+                  const uint32_t wi = sb[start + 2 * t], cw = sb[start + 2 * t + 1];
+                  const Fr w = W[(size_t)wi * P + p];
+                  if (cw & COEFF_ONE) acc = acc + w;
+                  else if (cw & COEFF_MINUS_ONE) acc = acc - w;
+                  else acc = acc + dc.coeffs[cw & COEFF_MASK] * w;
+                }
+                return acc;
+              };
+              Fr av = dot(base + 4, nA), bv = dot(base + 4 + 2 * nA, nB), rest = dot(base + 4 + 2 * (nA + nB), nC);
+              for (uint32_t off = G >> 1; off >= 1; off >>= 1) {
+                bv = bv + lane_get(bv, lane ^ off);
+                av = av + lane_get(av, lane ^ off);
+                rest = rest + lane_get(rest, lane ^ off);
+              }
+              if (live && sub == 0) {
+                if (na_w >> 31) av = bv;
+                W[(size_t)out * P + p] = av * bv - rest;
+              }
+            }
+            pos += sb[pos + 1];
+            __syncthreads();
+          }
+          if (more) {
+            SPP_UNROLL for (uint32_t j = 0; j < COOP_CHUNK / 64; j++) lvl_buf[(ch + 1) & 1][lane + 64 * j] = pre[j];
+          }
+          __syncthreads();
+        }
+        break;
+      }
       case COOP_POSEIDON: {
         const uint32_t t = pr[a + 1], h0 = pr[a + 2], out0 = pr[a + 3];
         if (t == 3) coop_poseidon<3>(dc, dc.pos3_rc, dc.pos3_mds, 57, W, h0, out0, P, p, lane);

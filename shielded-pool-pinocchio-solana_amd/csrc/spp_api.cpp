@@ -84,6 +84,7 @@ struct spp_circuit {
   bool no_coop = false;           // SPP_NO_COOP=1 (diagnostic): always the one-lane-per-proof solver
   bool trace_items = false;       // SPP_COOP_TRACE=1 (diagnostic): one launch per item of the cooperative solver
   bool one_track = false;         // SPP_COOP_ONE_TRACK=1 (diagnostic): the independent tracks of a stretch one after the other
+  bool no_level_stream = false;   // SPP_NO_LEVEL_STREAM=1 (diagnostic): table-driven level items instead of the LDS-staged stream
   uint32_t row_r = 0, row_s = 0, row_rs = 0, n_rows = 0;
   uint64_t table_bytes = 0;
   MsmSet<Fq> A, B1, K, Z, CB, CS;
@@ -117,7 +118,31 @@ static int coop_plan(spp_circuit* c) {
   const Circuit& circ = c->circ;
   const auto& pr = circ.program;
   struct Item { uint32_t kind, a, b; };
-  std::vector<uint32_t> items, par, lvl_ptr{0}, lvl_rows;
+  std::vector<uint32_t> items, par, lvl_ptr{0}, lvl_rows, stream;
+  const Fr f_one = Fr::one(), f_mone = Fr::one().neg();
+  auto coeff_word = [&](uint32_t ci) -> uint32_t {
+    return ci | (circ.coeffs[ci] == f_one ? COEFF_ONE : circ.coeffs[ci] == f_mone ? COEFF_MINUS_ONE : 0u);
+  };
+  // one row of the level stream (see DevCoop::lvl_stream)
+  auto row_record = [&](uint32_t k, std::vector<uint32_t>& out) {
+    const bool square = [&] {
+      const uint32_t a0 = circ.A.rowptr[k], a1 = circ.A.rowptr[k + 1], b0 = circ.B.rowptr[k], b1 = circ.B.rowptr[k + 1];
+      if (a1 - a0 != b1 - b0) return false;
+      for (uint32_t i = 0; i < a1 - a0; i++)
+        if (circ.A.terms[a0 + i].wire != circ.B.terms[b0 + i].wire || circ.A.terms[a0 + i].coeff != circ.B.terms[b0 + i].coeff) return false;
+      return true;
+    }();
+    const uint32_t nA = square ? 0 : circ.A.rowptr[k + 1] - circ.A.rowptr[k], nB = circ.B.rowptr[k + 1] - circ.B.rowptr[k],
+                   nC = circ.C.rowptr[k + 1] - circ.C.rowptr[k] - 1;
+    out.push_back(circ.C.terms[circ.C.rowptr[k + 1] - 1].wire);
+    out.push_back(nA | (square ? 0x80000000u : 0u));
+    out.push_back(nB);
+    out.push_back(nC);
+    auto put = [&](const Sparse& m, uint32_t n) {
+      for (uint32_t t = m.rowptr[k]; t < m.rowptr[k] + n; t++) { out.push_back(m.terms[t].wire); out.push_back(coeff_word(m.terms[t].coeff)); }
+    };
+    put(circ.A, nA); put(circ.B, nB); put(circ.C, nC);
+  };
   std::vector<uint32_t> level_of(circ.n_wires + 3, 0), stamp(circ.n_wires + 3, 0), writer(circ.n_wires + 3, 0);
   uint32_t epoch = 0;
   auto op_len = [&](size_t pc) -> uint32_t {
@@ -257,16 +282,70 @@ static int coop_plan(spp_circuit* c) {
         for (uint32_t cid : comp_order) {
           const uint32_t l0 = (uint32_t)lvl_ptr.size() - 1;
           uint32_t cur = 0xffffffffu;
+          std::vector<std::vector<uint32_t>> by_level;      // constraints of this component, level by level
           for (size_t oi : order) {
             if (comp_id[oi] != cid) continue;
             if (rows[oi].first != cur) {
               if (cur != 0xffffffffu) lvl_ptr.push_back((uint32_t)lvl_rows.size());
               cur = rows[oi].first;
+              by_level.emplace_back();
             }
             lvl_rows.push_back(rows[oi].second);
+            by_level.back().push_back(rows[oi].second);
           }
           lvl_ptr.push_back((uint32_t)lvl_rows.size());
-          push(COOP_LEVELS, l0, (uint32_t)lvl_ptr.size() - 1);
+          // the streamed form: levels as self-contained records in chunks of COOP_CHUNK words; a level too big for a chunk is cut
+          // into consecutive sub-levels (its rows are independent), a single row too big for one sends the component down the
+          // table-driven path
+          std::vector<uint32_t> local;          // this component's chunks
+          uint32_t used = 0;                    // words used in the current chunk
+          bool fits = !c->no_level_stream;
+          auto close_chunk = [&] {
+            if (used < COOP_CHUNK) local.push_back(0xffffffffu), used++;
+            local.resize(local.size() + (COOP_CHUNK - used), 0xffffffffu);
+            used = 0;
+          };
+          for (const auto& lv : by_level) {
+            if (!fits) break;
+            size_t i = 0;
+            while (i < lv.size() && fits) {
+              // greedily take rows while the sub-level record fits one chunk
+              std::vector<std::vector<uint32_t>> recs;
+              uint32_t words = 2;
+              while (i < lv.size()) {
+                std::vector<uint32_t> rec;
+                row_record(lv[i], rec);
+                if (words + 1 + rec.size() > COOP_CHUNK - 1) break;
+                words += 1 + (uint32_t)rec.size();
+                recs.push_back(std::move(rec));
+                i++;
+              }
+              if (recs.empty()) { fits = false; break; }
+              if (used + words > COOP_CHUNK - 1 && used) close_chunk();
+              // lanes per row: enough for the longest linear form of the sub-level (every extra doubling costs three shuffle-add
+              // rounds), at most 16, and rows x lanes within the wave when possible
+              uint32_t longest = 1;
+              for (const auto& rec : recs) longest = std::max({longest, rec[1] & 0x7fffffffu, rec[2], rec[3]});
+              uint32_t G = 1;
+              while (G < 16 && G < longest && recs.size() * (G * 2) <= 64) G *= 2;
+              uint32_t need = 0;
+              for (const auto& rec : recs) need |= ((rec[1] & 0x7fffffffu) ? 1u << 29 : 0u) | (rec[3] ? 1u << 30 : 0u);
+              local.push_back((uint32_t)recs.size() | (G << 24) | need);
+              local.push_back(words);
+              uint32_t off = 2 + (uint32_t)recs.size();
+              for (const auto& rec : recs) { local.push_back(off); off += (uint32_t)rec.size(); }
+              for (const auto& rec : recs) local.insert(local.end(), rec.begin(), rec.end());
+              used += words;
+            }
+          }
+          if (fits && !local.empty()) {
+            if (used) close_chunk();
+            const uint32_t chunk0 = (uint32_t)(stream.size() / COOP_CHUNK);
+            stream.insert(stream.end(), local.begin(), local.end());
+            push(COOP_LEVEL_STREAM, chunk0, (uint32_t)(local.size() / COOP_CHUNK));
+          } else {
+            push(COOP_LEVELS, l0, (uint32_t)lvl_ptr.size() - 1);
+          }
         }
         pc = e;
         seq0 = pc;
@@ -317,6 +396,23 @@ static int coop_plan(spp_circuit* c) {
           for (uint32_t r = lvl_ptr[it.a]; r < lvl_ptr[it.b]; r++) solve_c_rw(rw[i], lvl_rows[r]);
           rw[i].cost = 4.5 * (it.b - it.a);
           break;
+        case COOP_LEVEL_STREAM: {
+          uint32_t nlev = 0;
+          for (uint32_t ch = it.a; ch < it.a + it.b; ch++) {
+            const uint32_t* sb = stream.data() + (size_t)ch * COOP_CHUNK;
+            for (uint32_t pos = 0; pos < COOP_CHUNK && sb[pos] != 0xffffffffu; pos += sb[pos + 1]) {
+              nlev++;
+              for (uint32_t r = 0; r < (sb[pos] & 0xffffffu); r++) {
+                const uint32_t base = pos + sb[pos + 2 + r];
+                const uint32_t nt = (sb[base + 1] & 0x7fffffffu) + sb[base + 2] + sb[base + 3];
+                rw[i].wr.push_back(sb[base]);
+                for (uint32_t t = 0; t < nt; t++) rw[i].rd.push_back(sb[base + 4 + 2 * t]);
+              }
+            }
+          }
+          rw[i].cost = 3.0 * nlev;
+          break;
+        }
         default: op_rw(rw[i], it.a, true); break;
       }
     }
@@ -357,12 +453,13 @@ static int coop_plan(spp_circuit* c) {
   if (items.empty()) items.assign(3, 0);
   if (par.empty()) par.assign(2, 0);
   if (lvl_rows.empty()) lvl_rows.push_back(0);
-  uint32_t *d_items, *d_par, *d_lp, *d_lr;
+  if (stream.empty()) stream.assign(COOP_CHUNK, 0xffffffffu);
+  uint32_t *d_items, *d_par, *d_lp, *d_lr, *d_ls;
   int e;
   if ((e = own_upload(c, &d_items, items)) || (e = own_upload(c, &d_par, par)) || (e = own_upload(c, &d_lp, lvl_ptr)) ||
-      (e = own_upload(c, &d_lr, lvl_rows)))
+      (e = own_upload(c, &d_lr, lvl_rows)) || (e = own_upload(c, &d_ls, stream)))
     return e;
-  c->coop.items = d_items; c->coop.par = d_par; c->coop.lvl_ptr = d_lp; c->coop.lvl_rows = d_lr;
+  c->coop.items = d_items; c->coop.par = d_par; c->coop.lvl_ptr = d_lp; c->coop.lvl_rows = d_lr; c->coop.lvl_stream = d_ls;
   return 0;
 }
 
@@ -834,6 +931,7 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
     c->no_coop = getenv("SPP_NO_COOP") != nullptr || trace_ops;
     c->trace_items = getenv("SPP_COOP_TRACE") != nullptr;
     c->one_track = getenv("SPP_COOP_ONE_TRACK") != nullptr;
+    c->no_level_stream = getenv("SPP_NO_LEVEL_STREAM") != nullptr;
     uint32_t prev_op = OP_END;
     while (pc < pr.size() && pr[pc] != OP_END) {
       if (trace_ops && pr[pc] != prev_op) {
