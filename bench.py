@@ -169,11 +169,18 @@ def rlwe_leg(ctx, dev, pk, iters=200):
         assert (c0[i].cpu().numpy().astype(np.uint32) == oc0).all() and (k0[i].cpu().numpy() == ok0).all()
     cpu_s = (time.perf_counter() - t0) / len(sel)
     alg = 21504.0 * cnt + 8192     # 21 504 B per instance + the public key once
+    traffic = None
+    try:   # PMC passes of this leg, committed under profiles/ (rocprofv3 --pmc cannot run inside this process)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "round2_rlwe_pmc_hbm.json")))
+        if pmc.get("instances") == cnt:
+            traffic = pmc["hbm_bytes_per_launch"]
+    except Exception:
+        pass
     return {"metric": "RLWE witness instances/sec", "value": round(cnt / (ms * 1e-3), 1), "unit": "instances/s", "iters": iters,
             "config": {"workload": "2^16 RLWE instances: two negacyclic n=1024 products, 1088 exact quotients, 7x32-bit packing (BASELINE configs[3])"},
             "ms_per_batch": round(ms, 3),
             "roofline": {"bound": "hbm", "kernel": "k_rlwe_witness", "achieved": round(alg / (ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None, "alg_bytes_per_launch": int(alg)},
+                         "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": traffic, "alg_bytes_per_launch": int(alg)},
             "cpu_baseline": {"value": round(1.0 / cpu_s, 2), "unit": "instances/s", "cores": 1, "kind": "port",
                              "sample": "%d instances, oracle C schoolbook (the reference's CPython path: 1.4 instances/s/core, BASELINE.md)" % len(sel)}}
 
