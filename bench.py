@@ -205,12 +205,19 @@ def pippenger_leg(ctx, iters=10):
     t0 = time.perf_counter()
     native.lib().orc_msm_g1(bases, sc, ns, ctypes.cast(out, ctypes.c_void_p))
     cpu_s = time.perf_counter() - t0
+    traffic = None
+    try:   # PMC passes of this leg, committed under profiles/
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "round2_pippenger_pmc_hbm.json")))
+        if pmc.get("points") == n:
+            traffic = pmc["hbm_bytes_per_msm"]
+    except Exception:
+        pass
     return {"metric": "G1 MSM points/sec (Pippenger, general bases)", "value": round(n / (ms * 1e-3), 1), "unit": "points/s", "iters": iters,
             "config": {"workload": "2^24-point BN254 G1 MSM, uniform 253-bit scalars, bases k_i*G generated on device (BASELINE configs[4])"},
             "ms_per_msm": round(ms, 3),
             "witness_like_70pct_small": {"ms_per_msm": round(ms_w, 3), "points_per_s": round(n / (ms_w * 1e-3), 1), "bucket_kernel_ms": round(ms_bucket_w, 3)},
             "roofline": {"bound": "hbm", "kernel": "whole MSM (sort + bucket accumulation + reduction)", "achieved": round(alg / (ms * 1e-3) / 1e9, 3),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "alg_bytes_per_launch": int(alg), "bucket_kernel_ms": round(ms_bucket, 3)},
             "cpu_baseline": {"value": round(ns / cpu_s, 1), "unit": "points/s", "cores": native.max_threads(), "kind": "port",
                              "sample": "2^16-point MSM, oracle C Pippenger"}}
