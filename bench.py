@@ -548,9 +548,11 @@ def main():
         rows = [workload.row_ints(notes, 26, i) for i in range(B)]
         t0 = time.time()
         with mp.get_context("spawn").Pool(min(16, os.cpu_count() or 1)) as pool:
-            first = pool.map(ccs.complete_witness_worker, [(ccs_path, acir_path, r, None) for r in rows])
+            import secrets
+            masks = [secrets.randbelow(ccs.R) for _ in rows]          # gnark's hints.Randomize: the commitment's hiding mask
+            first = pool.map(ccs.complete_witness_worker, [(ccs_path, acir_path, r, None, m) for r, m in zip(rows, masks)])
             chal = h.commitment_challenge(b"".join(first))
-            full = pool.map(ccs.complete_witness_worker, [(ccs_path, acir_path, r, ch) for r, ch in zip(rows, chal)])
+            full = pool.map(ccs.complete_witness_worker, [(ccs_path, acir_path, r, ch, m) for r, ch, m in zip(rows, chal, masks)])
         witness_s = time.time() - t0
         inp = torch.frombuffer(bytearray(b"".join(full)), dtype=torch.uint8).to(dev)
         import random as _r

@@ -21,7 +21,7 @@
 /* ------------------------------------------------------------------------------------------------ */
 /* circuit container                                                                                 */
 /* ------------------------------------------------------------------------------------------------ */
-enum { OP_END, OP_SOLVE_C, OP_SOLVE_A, OP_BATCH_DIV, OP_BITS, OP_LIMBS8, OP_COUNT8, OP_POSEIDON, OP_POSEIDON2, OP_COMMIT, OP_GRUMPKIN, OP_INV_H };
+enum { OP_END, OP_SOLVE_C, OP_SOLVE_A, OP_BATCH_DIV, OP_BITS, OP_LIMBS8, OP_COUNT8, OP_POSEIDON, OP_POSEIDON2, OP_COMMIT, OP_GRUMPKIN, OP_INV_H, OP_MASK };
 
 typedef struct { uint32_t rows, nnz; uint32_t* rowptr; uint32_t* wire; uint32_t* coeff; } sparse_t;
 typedef struct {
@@ -297,7 +297,8 @@ static void solve_div_range(const circuit_t* c, fe* w, uint32_t k0, uint32_t n) 
   free(pre);
 }
 
-static int solve(const circuit_t* c, fe* w, challenge_fn chal, void* chal_ctx) {
+/* rs64: the proof's blinding factors r || s (32 B big-endian each): OP_MASK derives the commitment's random mask from them */
+static int solve(const circuit_t* c, fe* w, challenge_fn chal, void* chal_ctx, const uint8_t rs64[64]) {
   const uint32_t* pr = c->prog;
   uint32_t pc = 0;
   for (;;) {
@@ -425,6 +426,12 @@ static int solve(const circuit_t* c, fe* w, challenge_fn chal, void* chal_ctx) {
       case OP_COMMIT: {
         pc += 1;
         chal(chal_ctx, w, &w[c->challenge_wire]);
+        break;
+      }
+      case OP_MASK: {   /* fr.Hash(r || s): the hiding mask gnark's api.Commit adds (hints.Randomize) */
+        uint32_t out = pr[pc + 1];
+        pc += 2;
+        orc_hash_to_fr(rs64, 64, "bsb22-commitment", &w[out], 1);
         break;
       }
       default:
@@ -985,7 +992,15 @@ int orc_prove(void* ctx, const uint8_t* inputs, const uint8_t r32[32], const uin
   for (uint32_t i = 0; i < nin; i++) fe_from_be(&w[1 + i], inputs + 32 * (size_t)i, &FR);
   chal_ctx_t cc;
   cc.x = x;
-  if (solve(c, w, challenge_cb, &cc) != 0) { free(w); return -1; }
+  uint8_t rs64[64];
+  {   /* canonical r || s, as the device derives the mask from the reduced blinding factors */
+    fe rr_, ss_;
+    fe_from_be(&rr_, r32, &FR);
+    fe_from_be(&ss_, s32, &FR);
+    fe_to_be(rs64, &rr_, &FR);
+    fe_to_be(rs64 + 32, &ss_, &FR);
+  }
+  if (solve(c, w, challenge_cb, &cc, rs64) != 0) { free(w); return -1; }
   if (wires_out) for (uint32_t i = 0; i < W; i++) fe_to_be(wires_out + 32 * (size_t)i, &w[i], &FR);
 
   /* a, b, c evaluations + satisfaction check */
@@ -1088,7 +1103,8 @@ int orc_check_many(void* ctx, int count, const uint8_t* inputs, int32_t* first_u
     chal_ctx_t cc;
     cc.x = x;
     int32_t res = -1;
-    if (solve(c, w, challenge_cb, &cc) != 0) {
+    static const uint8_t zero_rs[64] = {0};
+    if (solve(c, w, challenge_cb, &cc, zero_rs) != 0) {
       res = -2;
     } else {
       for (uint32_t k = 0; k < c->n_constraints; k++) {

@@ -11,7 +11,7 @@ import struct
 from .bn254 import R, inv
 from . import hashes
 
-OP_END, OP_SOLVE_C, OP_SOLVE_A, OP_BATCH_DIV, OP_BITS, OP_LIMBS8, OP_COUNT8, OP_POSEIDON, OP_POSEIDON2, OP_COMMIT, OP_GRUMPKIN, OP_INV_H = range(12)
+OP_END, OP_SOLVE_C, OP_SOLVE_A, OP_BATCH_DIV, OP_BITS, OP_LIMBS8, OP_COUNT8, OP_POSEIDON, OP_POSEIDON2, OP_COMMIT, OP_GRUMPKIN, OP_INV_H, OP_MASK = range(13)
 
 
 class Sparse:
@@ -125,9 +125,16 @@ def _poseidon2_native(state, out, w):
     return out
 
 
-def solve(circ, inputs, challenge_fn):
+def mask_value(r, s):
+    """the commitment's random mask (OP_MASK): fr.Hash(r || s, "bsb22-commitment") of the proof's blinding factors"""
+    from .bn254 import hash_to_fr, DST_COMMITMENT
+    return hash_to_fr((r % R).to_bytes(32, "big") + (s % R).to_bytes(32, "big"), DST_COMMITMENT)[0]
+
+
+def solve(circ, inputs, challenge_fn, rs=(0, 0)):
     """inputs: public (without the constant) then secret values. challenge_fn(w) -> X is called at
-    OP_COMMIT with the partially solved witness (committed wires are all known by then)."""
+    OP_COMMIT with the partially solved witness (committed wires are all known by then).  rs: the proof's blinding
+    factors (the commitment mask is derived from them)."""
     assert len(inputs) == circ.n_inputs(), (len(inputs), circ.n_inputs())
     w = [0] * circ.n_wires
     w[0] = 1
@@ -214,6 +221,9 @@ def solve(circ, inputs, challenge_fn):
             pc += 3
             v = _dot(circ.H, h, w)
             w[out] = inv(v, R) if v else 0
+        elif op == OP_MASK:
+            w[prog[pc + 1]] = mask_value(*rs)
+            pc += 2
         elif op == OP_COMMIT:
             pc += 1
             w[circ.challenge_wire] = challenge_fn(w) % R

@@ -158,6 +158,13 @@ void Builder::finalize_lookups() {
     for (auto& e : v.t)
       if (e.first != 0) cw.push_back(e.first);
   for (int j = 0; j < 256; j++) cw.push_back(m0 + j);
+  // hiding: without it the commitment is a deterministic function of the committed values (limbs of secrets in a compiled
+  // program, the RLWE noise in the audit circuit) and two proofs over related witnesses could be linked through it.  gnark's
+  // api.Commit adds the same wire (hints.Randomize); here its value is derived from the proof's blinding factors.
+  const uint32_t mask = new_wire();
+  c_.program.push_back(OP_MASK);
+  c_.program.push_back(mask);
+  cw.push_back(mask);
   std::sort(cw.begin(), cw.end());
   cw.erase(std::unique(cw.begin(), cw.end()), cw.end());
   c_.committed = cw;

@@ -38,6 +38,8 @@ enum : uint32_t {
   OP_COMMIT = 9,      //              : phase boundary: the challenge wire is filled in before continuing
   OP_GRUMPKIN = 10,   // bit0 nbits aux_off n  w_0..w_{n-1} : slopes of the fixed-base Grumpkin ladder (see circuit.cpp)
   OP_INV_H = 11,      // h out        : w[out] = 1 / <H_h,w>  (0 when the form is 0); an UNCONSTRAINED hint (ACIR Brillig inverse)
+  OP_MASK = 12,       // out          : w[out] = fr.Hash(r || s): the random mask of the commitment (gnark: hints.Randomize inside
+                      //                api.Commit) -- a committed wire no constraint touches, so that the commitment hides the others
 };
 
 enum : uint32_t { CIRCUIT_WITHDRAW = 1, CIRCUIT_AUDIT = 2, CIRCUIT_ACIR = 5 };

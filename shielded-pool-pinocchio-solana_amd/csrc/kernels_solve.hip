@@ -11,6 +11,7 @@
 #include "kernels.hpp"
 #include "circuit.hpp"   // opcodes only
 #include "poseidon29.hpp"
+#include "sha256.hpp"
 
 namespace spp {
 
@@ -346,6 +347,17 @@ __device__ __forceinline__ void solve_range(const DevCircuit& dc, Fr* __restrict
         Fr s[4];
         SPP_UNROLL for (int i = 0; i < 4; i++) s[i] = dev_row_dot(dc.H, dc.coeffs, h0 + i, 0, W, P, p);
         dev_poseidon2(s, dc.p2_rc, dc.p2_mu, W, out0, P, p);
+        break;
+      }
+      case OP_MASK: {        // the commitment's random mask: fr.Hash(r || s) of the proof's blinding factors (rows n_wires, n_wires + 1)
+        const uint32_t out = pr[pc + 1];
+        pc += 2;
+        uint32_t m[16], cw[8];
+        W[(size_t)dc.n_wires * P + p].to_canonical(cw);
+        SPP_UNROLL for (int i = 0; i < 8; i++) m[i] = cw[7 - i];
+        W[(size_t)(dc.n_wires + 1) * P + p].to_canonical(cw);
+        SPP_UNROLL for (int i = 0; i < 8; i++) m[8 + i] = cw[7 - i];
+        W[(size_t)out * P + p] = bsb22_challenge(m);
         break;
       }
       case OP_GRUMPKIN: {

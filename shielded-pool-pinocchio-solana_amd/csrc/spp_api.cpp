@@ -147,7 +147,7 @@ static int coop_plan(spp_circuit* c) {
   uint32_t epoch = 0;
   auto op_len = [&](size_t pc) -> uint32_t {
     switch (pr[pc]) {
-      case OP_SOLVE_C: case OP_SOLVE_A: return 2;
+      case OP_SOLVE_C: case OP_SOLVE_A: case OP_MASK: return 2;
       case OP_BATCH_DIV: case OP_POSEIDON2: case OP_INV_H: return 3;
       case OP_COUNT8: case OP_BITS: case OP_LIMBS8: case OP_POSEIDON: return 4;
       case OP_COMMIT: return 1;
@@ -183,6 +183,7 @@ static int coop_plan(spp_circuit* c) {
         x.cost += 5 + 0.2 * pr[pc + 2];
         break;
       case OP_INV_H: row_rd(x, circ.H, pr[pc + 1], 0); x.wr.push_back(pr[pc + 2]); x.cost += 40; break;
+      case OP_MASK: x.wr.push_back(pr[pc + 1]); x.cost += 5; break;
       case OP_POSEIDON: {
         const uint32_t t = pr[pc + 1], nsbox = 8 * t + (t == 3 ? 57 : 60);
         for (uint32_t i = 0; i < t; i++) row_rd(x, circ.H, pr[pc + 2] + i, 0);
@@ -940,7 +941,7 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
       }
       prev_op = pr[pc];
       switch (pr[pc]) {
-        case OP_SOLVE_C: case OP_SOLVE_A: pc += 2; break;
+        case OP_SOLVE_C: case OP_SOLVE_A: case OP_MASK: pc += 2; break;
         case OP_BATCH_DIV:
           c->max_batch_div = std::max(c->max_batch_div, pr[pc + 2]);
           if (pr[pc + 2] >= 64) {

@@ -324,7 +324,6 @@ def decode_system(c):
 # gnark's solver loop on the decoded system
 # ---------------------------------------------------------------------------------------------------------------------
 UNSUPPORTED_HINTS = ()
-RANDOMIZER = 0x5EED        # what hints.Randomize returns here (gnark draws it at random)
 
 # Grumpkin's group order is the BN254 base field modulus; LAMBDA is the eigenvalue of its endomorphism (a cube root of unity mod Q).
 Q_BASE = 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47
@@ -408,7 +407,7 @@ def _emulated_mul_hint(ins, n_out):
     return k_l + r_l + carries
 
 
-def _hint_outputs(name, ins, n_out, challenge):
+def _hint_outputs(name, ins, n_out, challenge, randomizer=0x5EED):
     """The standard gnark hints of this system, restated from their documented behaviour (gnark 0.14: std/rangecheck,
     std/math/bits, constraint/solver, std/internal/logderivarg, internal/hints, frontend/cs)."""
     short = name.rsplit("/", 1)[-1]
@@ -439,19 +438,23 @@ def _hint_outputs(name, ins, n_out, challenge):
         return _limbs(s1, nl, bits) + _limbs(s2, nl, bits)
     if short == "emulated.mulHint":
         return _emulated_mul_hint(ins, n_out)
-    if short == "hints.Randomize":                          # any value satisfies the rows that use it; its wire is COMMITTED, so it
-        return [RANDOMIZER] * n_out                         # must not move with the challenge
+    if short == "hints.Randomize":                          # the random mask api.Commit adds to the committed wires (hiding): no row
+        return [randomizer] * n_out                         # uses it, and being committed it must not move with the challenge
     if short == "cs.Bsb22CommitmentComputePlaceholder":     # the commitment challenge: any value satisfies the rows
         return [challenge] * n_out
     return None
 
 
-def solve_partial(system, c, public_inputs, secret_by_name, challenge=0x5EED, challenge_fn=None):
+def solve_partial(system, c, public_inputs, secret_by_name, challenge=0x5EED, challenge_fn=None, randomizer=None):
     """-> (wires list with None for unknown, stats dict).  public_inputs: the five values after the constant wire;
     secret_by_name: {"__witness_<i>": value}.  challenge_fn(wires) -> the commitment challenge (what gnark's
     Bsb22CommitmentComputePlaceholder hint returns: the hash of the Pedersen commitment to the committed wires, which only the
     holder of the proving key can compute -- spp_commitment_challenge); without it the fixed `challenge` is used, which satisfies
-    the rows just as well but not a verifier."""
+    the rows just as well but not a verifier.  randomizer: the value of gnark's hints.Randomize (the commitment's hiding mask);
+    None draws a fresh one from the OS."""
+    if randomizer is None:
+        import secrets
+        randomizer = secrets.randbelow(R)
     w = [None] * system.n_wires
     w[0] = 1
     for i, v in enumerate(public_inputs):
@@ -489,7 +492,7 @@ def solve_partial(system, c, public_inputs, secret_by_name, challenge=0x5EED, ch
                 if ok and challenge_fn is not None and name.endswith("Bsb22CommitmentComputePlaceholder"):
                     outs = [challenge_fn(w) % R]
                 else:
-                    outs = _hint_outputs(name, vals, o1 - o0, challenge) if ok else None
+                    outs = _hint_outputs(name, vals, o1 - o0, challenge, randomizer) if ok else None
                 if outs is None:
                     stats["hints_skipped"].append((k, name.rsplit("/", 1)[-1]))
                     continue
@@ -599,10 +602,11 @@ _WORKER_CACHE = {}
 
 
 def complete_witness_worker(args):
-    """Process-pool worker (bench.py, batch drivers): (ccs path, acir path, input row, challenge | None) -> the witness row of the
+    """Process-pool worker (bench.py, batch drivers): (ccs path, acir path, input row, challenge | None, mask) -> the witness row of the
     container `to_sppc` writes, 32 B big-endian per wire.  challenge None: a placeholder is used -- the committed wires, hence the
-    commitment, do not depend on it -- and the caller repeats the call with the value spp_commitment_challenge returns."""
-    ccs_path, acir_path, row, challenge = args
+    commitment, do not depend on it -- and the caller repeats the call with the value spp_commitment_challenge returns and the
+    SAME mask (a fresh random field element per proof: it is one of the committed wires)."""
+    ccs_path, acir_path, row, challenge, randomizer = args
     key = (ccs_path, acir_path)
     if key not in _WORKER_CACHE:
         from . import acir
@@ -611,7 +615,8 @@ def complete_witness_worker(args):
     c, system, program, acir = _WORKER_CACHE[key]
     w = acir.execute(program, row)
     secret = {"__witness_%d" % k: v for k, v in w.items()}
-    wires, st = solve_partial(system, c, row[:len(c.public) - 1], secret, challenge=0x5EED if challenge is None else challenge)
+    wires, st = solve_partial(system, c, row[:len(c.public) - 1], secret, challenge=0x5EED if challenge is None else challenge,
+                              randomizer=randomizer)
     if st["rows_unsatisfied"] or st["rows_skipped"] or st["hints_skipped"]:
         raise ValueError("the inputs do not satisfy the reference's constraint system")
     return b"".join(v.to_bytes(32, "big") for v in wires[1:])

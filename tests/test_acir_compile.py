@@ -105,7 +105,7 @@ def test_compiled_circuit_every_input_and_every_wire_is_pinned(acir_circuit, wit
     c = C.Circuit(acir_circuit["sppc"])
     w = C.solve(c, good, lambda w_: 0xabc123)
     free = _free_wires(c, w, [1, random.Random(2).randrange(2, R)])
-    inv_hints = set()
+    inv_hints = set()      # free by design: inverse hints of a zero value, and the commitment's random mask (no constraint touches it)
     prog, pc = c.program, 0
     while prog[pc] != C.OP_END:
         op = prog[pc]
@@ -113,6 +113,10 @@ def test_compiled_circuit_every_input_and_every_wire_is_pinned(acir_circuit, wit
             if C._dot(c.H, prog[pc + 1], w) == 0:
                 inv_hints.add(prog[pc + 2])
             pc += 3
+        elif op == C.OP_MASK:
+            inv_hints.add(prog[pc + 1])
+            assert prog[pc + 1] in c.committed
+            pc += 2
         else:
             pc += {C.OP_SOLVE_C: 2, C.OP_SOLVE_A: 2, C.OP_BATCH_DIV: 3, C.OP_BITS: 4, C.OP_LIMBS8: 4, C.OP_COUNT8: 4, C.OP_POSEIDON: 4,
                    C.OP_POSEIDON2: 3, C.OP_COMMIT: 1}.get(op) or (5 + prog[pc + 4])
