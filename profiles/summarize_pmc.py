@@ -41,7 +41,7 @@ def main():
                       "hbm_bytes_per_launch_corrected": int((2 * fe["avg_kb"] + wr["avg_kb"]) * 1024)}
     doc = {"units": "KB per dispatch as reported; corrected HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024", "kernels": kernels}
     json.dump(doc, open(out, "w"), indent=1)
-    if len(sys.argv) >= 7:
+    if len(sys.argv) >= 7 and os.environ.get("SPP_WRITE_LATEST"):   # pmc_hbm_latest.json carries more keys: profiles/README of the round
         g1 = [v for k, v in kernels.items() if "k_msm_fixed<spp::Fp<spp::FqParams>" in k.replace(" ", "")
               or ("k_msm_fixed" in k and "FqParams" in k)]
         if g1:
