@@ -165,6 +165,9 @@ void Builder::finalize_lookups() {
   c_.program.push_back(OP_MASK);
   c_.program.push_back(mask);
   cw.push_back(mask);
+  // A committed wire's basis point is built from its columns of A, B, C; a wire in no constraint would get the point at infinity
+  // and mask nothing.  gnark gives its mask the row  mask * 1 = mask  (row 11 937 of the reference's .ccs); so does this builder.
+  constrain(LC::wire(mask), LC::constant(Fr::one()), LC::wire(mask));
   std::sort(cw.begin(), cw.end());
   cw.erase(std::unique(cw.begin(), cw.end()), cw.end());
   c_.committed = cw;
@@ -301,7 +304,7 @@ const Poseidon2Params& poseidon2_params() {
 // intermediate powers never enter the B matrix.  A wire on the B side costs a G1 and a G2 window walk (the G2 one
 // three times as expensive); x2*x2 = x4 would save a constraint but put x2 there.  Net: -1 B wire, +1 A/K wire per
 // S-box, about 8 % less MSM work per proof for the withdraw circuit.
-// The audit circuit's Poseidon2 sponge (4 664 S-boxes) uses the same form since round 2: 29 177 constraints instead of
+// The audit circuit's Poseidon2 sponge (4 664 S-boxes) uses the same form since round 2: 29 178 constraints instead of
 // 24 513, but 4 664 fewer wires in B -- the B1/B2 tables shrink by 21 GB, A/K grow by 14 GB, every set keeps its 11-bit
 // windows, and a proof needs about 8 % fewer additions (G1-equivalent).  sbox5_compact is kept for reference.
 static LC sbox5(Builder& b, const LC& x, bool solve) {

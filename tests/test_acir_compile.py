@@ -42,7 +42,7 @@ def test_reference_acir_compiles_to_a_small_r1cs(acir_circuit):
     c = C.Circuit(acir_circuit["sppc"])
     assert c.id == 1 and (c.n_public - 1, c.n_secret) == (5, 21)            # the withdraw ABI: usable by generateProof as is
     assert c.n_constraints == acir_circuit["n_constraints"] and 6000 < c.n_constraints < 8192 and c.domain_log == 13
-    # 12 452 constraints in the reference's gnark R1CS (emulated-field Grumpkin), 7 751 in the hand-written circuit.cpp
+    # 12 452 constraints in the reference's gnark R1CS (emulated-field Grumpkin), 7 752 in the hand-written circuit.cpp
     assert len(c.committed) > 0                                             # one BSB22 commitment: the 388-byte proof layout holds
 
 

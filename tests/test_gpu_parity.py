@@ -220,6 +220,9 @@ def test_withdraw_proof_bytes_match_oracle_and_verify(withdraw_handle, withdraw_
         assert proofs[i] == proof, "proof %d differs from the oracle" % i
     assert groth16.verify(vk, proofs[0], pws[0])
     assert groth16.verify(vk, proofs[3], pws[3])
+    # the commitment hides: the same inputs under other blinding factors give another commitment point (proof bytes 260..324)
+    again, _, st2 = withdraw_handle.prove_batch([rows[0], rows[0]], [rs[0], (rs[0][0] + 1, rs[0][1])])
+    assert st2 == [0, 0] and again[0] == proofs[0] and again[1][260:324] != proofs[0][260:324]
     bad = bytearray(proofs[0])
     bad[0] ^= 1                     # client/test-shielded-pool.ts:386-392 corrupts byte 0
     assert not groth16.verify(vk, bytes(bad), pws[0])
