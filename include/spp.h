@@ -127,7 +127,9 @@ int spp_sync(spp_circuit* c);
  * does between its two solver phases; out = count x 32 B big-endian.  For systems whose witness is completed OUTSIDE the library --
  * the reference's own gnark R1CS (noir_circuit/target/shielded_pool_verifier.ccs decoded by spp/ccs.py, every wire an input): the
  * wires after the commitment (the lookup argument's) depend on this value, gnark's solver gets it from the
- * Bsb22CommitmentComputePlaceholder hint (`sunspot prove`, client/proof.helper.ts:58-64).  Wires not known yet are passed as 0. */
+ * Bsb22CommitmentComputePlaceholder hint (`sunspot prove`, client/proof.helper.ts:58-64).  Wires not known yet are passed as 0.
+ * (Circuits built by spp_circuit_build* derive one committed wire, the hiding mask, from the blinding factors of the proof; this
+ * call has none and takes them as zero, so for those circuits its result is not the challenge of any real proof.) */
 int spp_commitment_challenge(spp_circuit* c, size_t count, const uint8_t* inputs, uint8_t* challenges);
 /* per-stage device time of the last spp_prove_batch_device call, milliseconds:
  * [0] witness solve (+commitment), [1] matrix eval, [2] NTT/QAP, [3] MSM G1, [4] wait for the G2 MSM (it runs on a side
