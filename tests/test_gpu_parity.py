@@ -1000,7 +1000,7 @@ def test_auditor_side_reconstruct_and_decrypt(ctx, rlwe_pk, rlwe_vectors):
 
 def test_small_batch_paths_agree_with_the_batch_paths(ctx, withdraw_artifacts, audit_artifacts, rlwe_pk, monkeypatch):
     """Batches up to 1024 proofs take the one-wave-per-proof solver (lane-parallel Poseidon / Poseidon2 / Grumpkin, SOLVE_C rows
-    by dependency level), batches up to 16 also replace s*Ar and r*Bs1 by table sums over the scaled witness, small launches split
+    by dependency level), small batches (144 withdraw / 31 audit proofs) also replace s*Ar and r*Bs1 by table sums over the scaled witness, small launches split
     the windows of a base over lanes and evaluate matrix rows 16 lanes at a time.  None of that may change a byte: the same rows
     and (full-size) blinding factors give the same proofs at batch sizes 1, 3, 17 (cooperative), through a handle loaded with
     SPP_NO_COOP=1 (always one lane per proof, lanes multiply the blinding), and inside a batch of 1100 (past the threshold)."""
