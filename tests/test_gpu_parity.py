@@ -1028,12 +1028,12 @@ def test_small_batch_paths_agree_with_the_batch_paths(ctx, withdraw_artifacts, a
                 workload.audit_rows(ctx, rlwe_pk["a"], rlwe_pk["b"], big, first=7)
             row_len = h.n_inputs * 32
             rs = b"".join(rng.randrange(R).to_bytes(32, "big") + rng.randrange(R).to_bytes(32, "big") for _ in range(big))
-            ref_p, ref_w = prove(h_lane, rows_b[:17 * row_len], 17, rs[:17 * 64])
-            for n in (1, 3, 17):
+            ref_p, ref_w = prove(h_lane, rows_b[:40 * row_len], 40, rs[:40 * 64])
+            for n in (1, 3, 17, 40):                    # 40 audit proofs: cooperative solver, 16-lane rows, per-lane blinding
                 p, w = prove(h, rows_b[:n * row_len], n, rs[:n * 64])
                 assert p == ref_p[:n] and w == ref_w[:n], (name, n)
             p, w = prove(h, rows_b, big, rs)            # > 1024: one lane per proof, blinding multiplied by the lanes
-            assert p[:17] == ref_p and w[:17] == ref_w, name
+            assert p[:40] == ref_p and w[:40] == ref_w, name
             tail_p, tail_w = prove(h, rows_b[(big - 2) * row_len:], 2, rs[(big - 2) * 64:])
             assert p[-2:] == tail_p and w[-2:] == tail_w, name
             assert all(ctx.verify_batch(open(art["vk"], "rb").read(), p[:64] + p[-64:], w[:64] + w[-64:]))
