@@ -401,6 +401,20 @@ __device__ __forceinline__ Fr lane_get(const Fr& v, uint32_t src) {
   SPP_UNROLL for (int i = 0; i < 8; i++) r.l[i] = (uint32_t)__shfl((int)v.l[i], (int)src);
   return r;
 }
+// the value of one FIXED lane in every lane: v_readlane_b32 (scalar path) instead of the LDS crossbar of ds_bpermute
+template <int SRC>
+__device__ __forceinline__ Fr lane_bcast(const Fr& v) {
+  Fr r;
+  SPP_UNROLL for (int i = 0; i < 8; i++) r.l[i] = (uint32_t)__builtin_amdgcn_readlane((int)v.l[i], SRC);
+  return r;
+}
+// lane ^ 1 / lane ^ 2 inside each quad: one DPP move per word (quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E)
+template <int CTRL>
+__device__ __forceinline__ Fr lane_quad(const Fr& v) {
+  Fr r;
+  SPP_UNROLL for (int i = 0; i < 8; i++) r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[i], CTRL, 0xF, 0xF, true);
+  return r;
+}
 __device__ __forceinline__ Fr lane_sel(bool c, const Fr& a, const Fr& b) {
   Fr r;
   SPP_UNROLL for (int i = 0; i < 8; i++) r.l[i] = c ? a.l[i] : b.l[i];
@@ -423,7 +437,7 @@ __device__ __noinline__ void coop_poseidon2(const DevCircuit& dc, Fr* __restrict
   if (lane < 4) s = dev_row_dot(dc.H, dc.coeffs, h0 + lane, 0, W, P, p);
   const Fr mu = dc.p2_mu[l4];
   auto external = [&](const Fr& mine) {   // rows (5,7,1,3),(4,6,1,1),(1,3,5,7),(1,1,4,6) of the state held by lanes 0..3
-    const Fr x = lane_get(mine, 0), y = lane_get(mine, 1), z = lane_get(mine, 2), w = lane_get(mine, 3);
+    const Fr x = lane_bcast<0>(mine), y = lane_bcast<1>(mine), z = lane_bcast<2>(mine), w = lane_bcast<3>(mine);
     const Fr t0 = x + y, t1 = z + w, t2 = y.dbl() + t1, t3 = w.dbl() + t0;
     const Fr t4 = t1.dbl().dbl() + t3, t5 = t0.dbl().dbl() + t2;
     const Fr t6 = t3 + t5, t7 = t2 + t4;
@@ -448,20 +462,20 @@ __device__ __noinline__ void coop_poseidon2(const DevCircuit& dc, Fr* __restrict
 #pragma unroll 1
   for (int r = 0; r < 56; r++) {
     const Fr x = s + dc.p2_rc[k];                        // lane 0
-    const Fr x0 = lane_get(x, 0);
+    const Fr x0 = lane_bcast<0>(x);
     const Fr R1 = lane_sel(lane == 0, x0, lane_sel(lane < 4, s, x0)) * lane_sel(lane == 0, x0, mu);
     // R1: lane 0 x^2 | lanes 1..3 mu_i * s_i | lane 4 mu_0 * x
-    const Fr x2 = lane_get(R1, 0);
+    const Fr x2 = lane_bcast<0>(R1);
     const Fr R2 = x2 * lane_sel(lane == 0, x0, x2);      // lane 0 x^3 | lane 4 x^4
-    const Fr x4 = lane_get(R2, 4);
+    const Fr x4 = lane_bcast<4>(R2);
     const Fr R3 = x4 * lane_sel(lane == 0, x0, R1);      // lane 0 x^5 | lane 4 mu_0 * x^5
     if (lane == 0) emit4(W, out, P, p, R1, R2, x4, R3);
     out += 4;
     k += 1;
     const Fr val = lane_sel(lane == 0, R3, s);
-    Fr tot = val + lane_get(val, lane ^ 1);
-    tot = tot + lane_get(tot, lane ^ 2);
-    const Fr m0 = lane_get(R3, 4);
+    Fr tot = val + lane_quad<0xB1>(val);
+    tot = tot + lane_quad<0x4E>(tot);
+    const Fr m0 = lane_bcast<4>(R3);
     s = lane_sel(lane == 0, m0, R1) + tot;
   }
 #pragma unroll 1
@@ -499,13 +513,13 @@ __device__ __noinline__ void coop_poseidon(const DevCircuit& dc, const Fr* __res
       SPP_UNROLL for (int j = 1; j < T; j++) acc = acc + lane_get(prod, 16 + li * T + j);
       s = acc;
     } else {
-      const Fr x0 = lane_get(s, 0);
+      const Fr x0 = lane_bcast<0>(s);
       const Fr sj = lane_get(s, qj);
       // lane 0: x * x | lanes 8+i: M[i][0] * x | lanes 16+i*T+j: M[i][j] * s_j
       const Fr R1 = lane_sel(lane == 0, x0, lane_sel(is_y, my, mq)) * lane_sel(lane == 0 || is_y, x0, sj);
-      const Fr x2 = lane_get(R1, 0);
+      const Fr x2 = lane_bcast<0>(R1);
       const Fr R2 = x2 * lane_sel(lane == 0, x0, x2);            // lane 0: x^3 ; lane 1: x^4
-      const Fr x4 = lane_get(R2, 1);
+      const Fr x4 = lane_bcast<1>(R2);
       const Fr R3 = x4 * lane_sel(lane == 0, x0, R1);            // lane 0: x^5 ; lanes 8+i: M[i][0] * x^5
       if (lane == 0) emit4(W, out, P, p, R1, R2, x4, R3);
       out += 4;
