@@ -1034,6 +1034,9 @@ def test_small_batch_paths_agree_with_the_batch_paths(ctx, withdraw_artifacts, a
                 assert p == ref_p[:n] and w == ref_w[:n], (name, n)
             p, w = prove(h, rows_b, big, rs)            # > 1024: one lane per proof, blinding multiplied by the lanes
             assert p[:40] == ref_p and w[:40] == ref_w, name
+            # 1024 distinct rows, the largest cooperative batch, proof by proof against the batch result
+            pc, wc = prove(h, rows_b[:1024 * row_len], 1024, rs[:1024 * 64])
+            assert pc == p[:1024] and wc == w[:1024], name
             tail_p, tail_w = prove(h, rows_b[(big - 2) * row_len:], 2, rs[(big - 2) * 64:])
             assert p[-2:] == tail_p and w[-2:] == tail_w, name
             assert all(ctx.verify_batch(open(art["vk"], "rb").read(), p[:64] + p[-64:], w[:64] + w[-64:]))
