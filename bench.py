@@ -610,7 +610,10 @@ def main():
         extras["withdraw_at_reference_r1cs_size"] = run_circuit("withdraw_refshape", DEFAULT_BATCH["withdraw_refshape"], 10, 3, False)
         extras["withdraw_depth20_variant"] = run_circuit("withdraw_depth20", DEFAULT_BATCH["withdraw_depth20"], 10, 3, False)
         extras["withdraw_compiled_from_reference_acir"] = run_circuit("withdraw_acir", DEFAULT_BATCH["withdraw_acir"], 10, 3, False)
-        extras["withdraw_reference_gnark_r1cs"] = reference_r1cs_leg()
+        try:     # an auxiliary leg with a host-side process pool: a failure here must not cost the headline line
+            extras["withdraw_reference_gnark_r1cs"] = reference_r1cs_leg()
+        except Exception as e:   # noqa: BLE001
+            extras["withdraw_reference_gnark_r1cs"] = {"error": "%s: %s" % (type(e).__name__, e)}
         ctx = spp.Context(local_rank)
         extras["rlwe_witness_2p16"] = rlwe_leg(ctx, dev, rlwe_pk)
         extras["msm_g1_2p24"] = pippenger_leg(ctx)
