@@ -97,7 +97,7 @@ void spp_free_ctx(spp_ctx* ctx);
 int spp_setup(spp_ctx* ctx, const char* circuit_path, const uint8_t seed[32], const char* pk_path, const char* vk_path);
 
 /* Loads R1CS + proving key, builds the window tables in HBM. window_bits in [4,16] = the same window for every MSM set;
- * 0 = per-set windows chosen greedily within env SPP_TABLE_BUDGET_GB (default 240) and 85 % of the free HBM; env SPP_SERIAL=1 (profiling aid) puts both batch workspaces and the G2 MSM on one stream. */
+ * 0 = per-set windows chosen greedily within env SPP_TABLE_BUDGET_GB (default 240) and 85 % of the free HBM, single-row tables walked once per window (16 bits = 16 additions per scalar); env SPP_SERIAL=1 (profiling aid) puts both batch workspaces and the G2 MSM on one stream. */
 int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const char* pk_path, int window_bits, spp_circuit** out);
 void spp_free_circuit(spp_circuit* c);
 /* info[0..7] = id, n_public (without the constant), n_secret, n_wires, n_constraints, domain_log, n_inputs, window_bits */
@@ -106,6 +106,9 @@ int spp_circuit_info(const spp_circuit* c, uint32_t info[8]);
 int spp_circuit_msm_sizes(const spp_circuit* c, uint32_t sizes[7]);
 /* window bits of the table of each of those sets (same order) */
 int spp_circuit_msm_windows(const spp_circuit* c, uint32_t bits[7]);
+/* table rows per base of each of those sets (same order): 1 = one row of 2^(bits-1) multiples, walked once per window
+ * (the throughput layout chosen with window_bits = 0); ceil(254 / bits) = one row per window (explicit window_bits) */
+int spp_circuit_msm_table_rows(const spp_circuit* c, uint32_t rows[7]);
 /* exact bytes of HBM held by the window tables */
 uint64_t spp_circuit_table_bytes(const spp_circuit* c);
 

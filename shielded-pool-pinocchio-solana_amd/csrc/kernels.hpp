@@ -145,34 +145,47 @@ void launch_ntt(hipStream_t st, Fr* data, uint32_t logn, uint32_t P, const Fr* t
 void launch_scale_rows(hipStream_t st, Fr* data, const Fr* table, uint32_t n, uint32_t P, uint32_t nbatch, size_t batch_stride);
 void launch_qap_pointwise(hipStream_t st, Fr* abc, uint32_t n, uint32_t P, Fr zinv);
 
-// ---- MSM with precomputed window tables ----
-// builds rows [row0, row0 + nrows) (row = base * windows + window; row0 a multiple of 64) of the table of N bases;
+// ---- MSM with precomputed window tables (kernels_msm.hip) ----
+// A base carries Wt table rows of 2^(c-1) affine multiples; row m = multiples of 2^(c*R*m) * Base, R = ceil(W / Wt) window passes
+// (W = ceil(254 / c) windows per scalar).  Wt = W: one row per window, no passes (the small-table latency layout).  Wt = 1: one row
+// per base and W passes whose sums are combined by Horner (the throughput layout: widest window for the bytes).
+uint32_t msm_windows(uint32_t c);
+struct MsmPlan {
+  uint32_t W;        // windows per scalar
+  uint32_t Wt, R;    // table rows per base, passes
+  uint32_t Q, Wq;    // small batches: Q lanes share the rows of a base, Wq rows each
+  uint32_t Sg;       // slices of the item range per pass
+  uint32_t Pp;       // proofs per slice row: P rounded up to a wave (P >= 64), else P
+  size_t partial_elems(uint32_t P) const { return (size_t)R * Sg * P; }
+};
+MsmPlan msm_plan(uint32_t N, uint32_t P, uint32_t c, uint32_t Wt);
+// builds rows [row0, row0 + nrows) (row = base * Wt + m; row0 a multiple of 64) of the table of N bases;
 // tmp / tmp_pre: nrows * 2^(c-1) elements each.  Layout: see kernels_msm.hip.
 template <class F>
-void launch_build_table(hipStream_t st, const Affine<F>* bases, uint32_t N, uint32_t c, uint32_t row0, uint32_t nrows, Affine<F>* table,
-                        XYZZ<F>* tmp, F* tmp_pre);
-size_t msm_table_elems(uint32_t N, uint32_t c);
-// lane g -> (slice g / P, proof g % P); partial[S][P]
+void launch_build_table(hipStream_t st, const Affine<F>* bases, uint32_t N, uint32_t c, uint32_t Wt, uint32_t row0, uint32_t nrows,
+                        Affine<F>* table, XYZZ<F>* tmp, F* tmp_pre);
+size_t msm_table_elems(uint32_t N, uint32_t c, uint32_t Wt);
+// signed c-bit digits of scalars[rows[i]][p] as int16 planes dig[j][i][p] (Pp per row); msm_digit_elems = W * N * Pp
+size_t msm_digit_elems(uint32_t N, uint32_t P, uint32_t c);
+void launch_msm_digits(hipStream_t st, const uint32_t* rows, const Fr* scalars, int16_t* dig, uint32_t N, uint32_t P, uint32_t c);
+// lane g -> (pass, slice, proof); partial[R * Sg][P]
 template <class F>
-void launch_msm_accumulate(hipStream_t st, const Affine<F>* table, const uint32_t* rows, const Fr* scalars, XYZZ<F>* partial, uint32_t N,
-                           uint32_t P, uint32_t c, uint32_t S, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, uint32_t Q = 1);
-// out[p] = sum_s partial[s][p]   (S = 0: out[p] = infinity); folds in place: `partial` is scratch afterwards
+void launch_msm_accumulate(hipStream_t st, const Affine<F>* table, const int16_t* dig, XYZZ<F>* partial, uint32_t N, uint32_t P, uint32_t c,
+                           const MsmPlan& pl, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// out[p] = sum over slices and passes (empty: out[p] = infinity); folds in place: `partial` is scratch afterwards
 template <class F>
-void launch_msm_reduce(hipStream_t st, XYZZ<F>* partial, XYZZ<F>* out, uint32_t P, uint32_t S);
-// several sets folded by the same launches (one launch per level for all of them)
+void launch_msm_reduce(hipStream_t st, XYZZ<F>* partial, XYZZ<F>* out, uint32_t P, const MsmPlan& pl, uint32_t c, bool empty);
+// several sets folded by the same launches (one launch per level for all of them, one Horner launch)
 static constexpr uint32_t MSM_FOLD_SETS = 8;
 template <class F>
 struct MsmFoldSets {
   XYZZ<F>* partial[MSM_FOLD_SETS];
   XYZZ<F>* out[MSM_FOLD_SETS];
-  uint32_t cur[MSM_FOLD_SETS], half[MSM_FOLD_SETS];   // filled per level by launch_msm_reduce_multi
+  uint32_t Sg[MSM_FOLD_SETS], R[MSM_FOLD_SETS], c[MSM_FOLD_SETS];   // per set: slices per pass (0 = empty set), passes, window bits
+  uint32_t cur[MSM_FOLD_SETS], half[MSM_FOLD_SETS];                 // filled per level by launch_msm_reduce_multi
 };
 template <class F>
-void launch_msm_reduce_multi(hipStream_t st, MsmFoldSets<F> fs, uint32_t nsets, const uint32_t* S, uint32_t P);
-uint32_t msm_windows(uint32_t c);
-uint32_t msm_slices(uint32_t N, uint32_t P);
-uint32_t msm_window_chunks(uint32_t N, uint32_t P, uint32_t c);   // Q: lanes per base for small batches (1 = none)
-uint32_t msm_slices_split(uint32_t N, uint32_t P, uint32_t Q);
+void launch_msm_reduce_multi(hipStream_t st, MsmFoldSets<F> fs, uint32_t nsets, uint32_t P);
 
 // ---- general-base Pippenger (kernels_pippenger.hip) ----
 size_t pippenger_workspace_bytes(uint32_t n);

@@ -5,14 +5,16 @@
 // inside `sunspot prove` (client/proof.helper.ts:64) on CPU threads, one proof at a time.
 //
 // MI355X design: the proving key is constant across a batch and there are 288 GB of HBM, so every base
-// carries a precomputed table of its window multiples  T[i][j][d] = (d+1) * 2^(c*j) * Base_i  (affine,
-// d < 2^(c-1), signed digits).  An MSM then needs no buckets, no sorting and no bucket reduction: each
-// lane owns one proof of the batch and folds  sum_i sum_j  +-T[i][j][|digit|]  into a private XYZZ
-// accumulator with mixed additions (8M+2S).  All 64 lanes of a wave walk the SAME (i, j) sequence, so
-// scalar loads are one coalesced 2 KiB row, table gathers hit one 2^(c-1)*64 B segment, control flow is
-// uniform, and windows in which every proof has a zero digit (bits, bytes, small signed noise -- most of
-// the audit witness) are skipped for the whole wave.  Work is split over S slices of the base range to
-// fill 256 CUs; the S partial sums of every proof are then folded pairwise (k_msm_fold, log2 S launches).
+// carries a precomputed table of its multiples (affine, signed c-bit digits: 2^(c-1) entries per row).  An MSM
+// then needs no buckets, no sorting and no bucket reduction: each lane owns one proof of the batch and folds
+// +-T[base][|digit|] into a private XYZZ accumulator with mixed additions (8M+2S).  The scalars are recoded once
+// into int16 digit planes (k_msm_digits); all 64 lanes of a wave walk the SAME (base, window) sequence, so digit
+// loads are one coalesced row, table gathers hit one 2^(c-1)*64 B segment, control flow is uniform, and windows in
+// which every proof has a zero digit (bits, bytes, small signed noise -- most of the audit witness) are skipped for
+// the whole wave.  Under the HBM budget a base keeps ONE row (16-bit windows, 2 MB per G1 base) and the 16 windows
+// of a scalar become 16 passes over the same table whose sums are put together by Horner (k_msm_horner); with
+// explicit small windows every window has its own row and there is a single pass.  Work is split over passes and
+// slices of the base range to fill 256 CUs; the slice sums of every (pass, proof) are folded pairwise.
 #include <hip/hip_ext.h>
 #include "kernels.hpp"
 #include <algorithm>
@@ -23,38 +25,38 @@ namespace spp {
 
 uint32_t msm_windows(uint32_t c) { return (254 + c - 1) / c; }
 
-// Window chunks per base for small batches (1 = a lane takes whole bases): when 4 bases per slice cannot give ~64K lanes, the
-// windows of a base are split over up to 8 lanes (>= 4 windows each); msm_slices(N * Q', P) lanes then share the items.
-uint32_t msm_window_chunks(uint32_t N, uint32_t P, uint32_t c) {
-  const uint32_t Wn = msm_windows(c);
-  const uint64_t target = 65536;
-  uint32_t Q = 1;
-  while ((uint64_t)((N + 3) / 4) * Q * P < target && Q < 8 && (Wn + 2 * Q - 1) / (2 * Q) >= 4) Q *= 2;
-  return Q;
-}
-uint32_t msm_slices_split(uint32_t N, uint32_t P, uint32_t Q) {
-  if (Q <= 1) return msm_slices(N, P);
-  const uint64_t items = (uint64_t)N * Q;
-  uint64_t S = (65536 + P - 1) / P;
-  if (S > items) S = items;
-  if (S == 0) S = 1;
-  return (uint32_t)S;
-}
-
-// enough (slice, proof) lanes to fill 256 CUs x 4 SIMDs x ~4 waves, but at least 4 bases per slice
-uint32_t msm_slices(uint32_t N, uint32_t P) {
+// Lane layout of one launch (see kernels.hpp, MsmPlan).  Big batches: ~256 CUs x 4 SIMDs x 4 waves of lanes, at least 4 bases
+// per slice.  Small batches (a single proof is the drop-in generateProof case): when that cannot give ~64K lanes the table
+// windows of a base are shared by up to 8 lanes (Q chunks of >= 4 windows) and a slice may be a single (base, chunk) item.
+MsmPlan msm_plan(uint32_t N, uint32_t P, uint32_t c, uint32_t Wt) {
   static const uint32_t waves_per_simd = [] {   // SPP_MSM_WAVES (experiment): lanes launched = 256 CUs x 4 SIMDs x this x 64
     const char* e = getenv("SPP_MSM_WAVES");
     const int v = e ? atoi(e) : 4;
     return (uint32_t)(v >= 1 && v <= 8 ? v : 4);
   }();
-  const uint32_t target_lanes = 256u * 4u * waves_per_simd * 64u;
-  uint32_t S = (target_lanes + P - 1) / P;
-  uint32_t maxS = (N + 3) / 4;
+  MsmPlan pl{};
+  pl.W = msm_windows(c);
+  if (Wt == 0 || Wt > pl.W) Wt = pl.W;
+  pl.Wt = Wt;
+  pl.R = (pl.W + Wt - 1) / Wt;
+  pl.Pp = P >= 64 ? (P + 63) / 64 * 64 : P;
+  pl.Q = 1;
+  const uint64_t lanes_per_slice = (uint64_t)(pl.Pp ? pl.Pp : 1) * pl.R;
+  while ((uint64_t)((N + 3) / 4) * pl.Q * lanes_per_slice < 65536 && pl.Q < 8 && (Wt + 2 * pl.Q - 1) / (2 * pl.Q) >= 4) pl.Q *= 2;
+  pl.Wq = (Wt + pl.Q - 1) / pl.Q;
+  uint64_t S, maxS;
+  if (pl.Q > 1) {
+    S = (65536 + lanes_per_slice - 1) / lanes_per_slice;
+    maxS = (uint64_t)N * pl.Q;
+  } else {
+    S = ((uint64_t)256 * 4 * waves_per_simd * 64 + lanes_per_slice - 1) / lanes_per_slice;
+    maxS = (N + 3) / 4;
+  }
   if (maxS == 0) maxS = 1;
   if (S > maxS) S = maxS;
   if (S == 0) S = 1;
-  return S;
+  pl.Sg = (uint32_t)S;
+  return pl;
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -65,7 +67,7 @@ uint32_t msm_slices(uint32_t N, uint32_t P) {
 // ----------------------------------------------------------------------------------------------------
 template <class F>
 __global__ void __launch_bounds__(64) k_build_table(const Affine<F>* __restrict__ bases, uint32_t N, uint32_t c, uint32_t Wn,
-                                                    uint32_t row0, uint32_t nrows, Affine<F>* __restrict__ table,
+                                                    uint32_t step_bits, uint32_t row0, uint32_t nrows, Affine<F>* __restrict__ table,
                                                     XYZZ<F>* __restrict__ tmp, F* __restrict__ tmp_pre) {
   const uint32_t rl = blockIdx.x * blockDim.x + threadIdx.x;   // row within this launch (row0 is a multiple of 64)
   if (rl >= nrows) return;
@@ -85,7 +87,7 @@ __global__ void __launch_bounds__(64) k_build_table(const Affine<F>* __restrict_
     return;
   }
   XYZZ<F> b = XYZZ<F>::from_affine(base);
-  for (uint32_t k = 0; k < c * j; k++) b.dbl_inplace();
+  for (uint32_t k = 0; k < step_bits * j; k++) b.dbl_inplace();
   Affine<F> bj = b.to_affine();
   XYZZ<F> acc = XYZZ<F>::from_affine(bj);
   F prod = F::one();
@@ -106,22 +108,26 @@ __global__ void __launch_bounds__(64) k_build_table(const Affine<F>* __restrict_
   }
 }
 
-// number of table elements (points) for N bases at window c, including the padding of the last 64-row block
-size_t msm_table_elems(uint32_t N, uint32_t c) {
-  size_t rows = (size_t)N * msm_windows(c);
+// number of table elements (points) for N bases with Wt window rows each, including the padding of the last 64-row block
+size_t msm_table_elems(uint32_t N, uint32_t c, uint32_t Wt) {
+  if (Wt == 0 || Wt > msm_windows(c)) Wt = msm_windows(c);
+  size_t rows = (size_t)N * Wt;
   return ((rows + 63) / 64) * 64 * ((size_t)1 << (c - 1));
 }
 
 template <class F>
-void launch_build_table(hipStream_t st, const Affine<F>* bases, uint32_t N, uint32_t c, uint32_t row0, uint32_t nrows, Affine<F>* table,
-                        XYZZ<F>* tmp, F* tmp_pre) {
+void launch_build_table(hipStream_t st, const Affine<F>* bases, uint32_t N, uint32_t c, uint32_t Wt, uint32_t row0, uint32_t nrows,
+                        Affine<F>* table, XYZZ<F>* tmp, F* tmp_pre) {
   if (nrows == 0) return;
-  hipLaunchKernelGGL(k_build_table<F>, dim3((nrows + 63) / 64), dim3(64), 0, st, bases, N, c, msm_windows(c), row0, nrows, table, tmp,
-                     tmp_pre);
+  const uint32_t W = msm_windows(c);
+  if (Wt == 0 || Wt > W) Wt = W;
+  const uint32_t R = (W + Wt - 1) / Wt;   // row m of a base holds the multiples of 2^(c*R*m) * Base (pass rho takes windows rho + R*m)
+  hipLaunchKernelGGL(k_build_table<F>, dim3((nrows + 63) / 64), dim3(64), 0, st, bases, N, c, Wt, c * R, row0, nrows, table, tmp, tmp_pre);
 }
-template void launch_build_table<Fq>(hipStream_t, const Affine<Fq>*, uint32_t, uint32_t, uint32_t, uint32_t, Affine<Fq>*, XYZZ<Fq>*, Fq*);
-template void launch_build_table<Fq2>(hipStream_t, const Affine<Fq2>*, uint32_t, uint32_t, uint32_t, uint32_t, Affine<Fq2>*, XYZZ<Fq2>*,
-                                      Fq2*);
+template void launch_build_table<Fq>(hipStream_t, const Affine<Fq>*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, Affine<Fq>*,
+                                     XYZZ<Fq>*, Fq*);
+template void launch_build_table<Fq2>(hipStream_t, const Affine<Fq2>*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, Affine<Fq2>*,
+                                      XYZZ<Fq2>*, Fq2*);
 
 // ----------------------------------------------------------------------------------------------------
 // signed-window recoding helpers (scalar in canonical limbs, magnitude < 2^253 after sign folding)
@@ -165,7 +171,71 @@ struct Recoder {
 };
 
 // ----------------------------------------------------------------------------------------------------
-// MSM accumulate: lane g -> (slice = g / P, proof p = g % P)
+// Digit planes.  One lane per (base, proof): the scalar is brought to canonical form ONCE, folded to its magnitude
+// (scalars above (r-1)/2 become their negatives: the small signed noise of the audit witness stays small), recoded into
+// W = ceil(254/c) signed c-bit digits and stored as int16 planes  dig[j][i][p]  (p fastest, Pp per row).  Digits lie in
+// [-2^(c-1), 2^(c-1) - 1] -- for a folded (negated) scalar the recoding keeps +2^(c-1) and carries above it, so that the
+// negated digit is -2^(c-1) -- which is what lets c = 16 fit int16.  The accumulate kernels then read 2 bytes per (window,
+// base, proof), coalesced, with no recoder state in registers and no carry chain between windows: any window can be
+// processed by any lane, which is what the window passes below need.
+// ----------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_msm_digits(const uint32_t* __restrict__ rows, const Fr* __restrict__ scalars,
+                                                    int16_t* __restrict__ dig, uint32_t N, uint32_t P, uint32_t Pp, uint32_t c, uint32_t W) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t p = (uint32_t)(g % Pp), i = (uint32_t)(g / Pp);
+  if (i >= N || p >= P) return;
+  const Fr s = scalars[(size_t)rows[i] * P + p];
+  uint32_t l[8];
+  s.to_canonical(l);
+  const bool neg = canonical_gt_half<FrParams>(l);
+  if (neg) {
+    uint32_t t[8];
+    canonical_negate<FrParams>(l, t);
+    SPP_UNROLL for (int k = 0; k < 8; k++) l[k] = t[k];
+  }
+  const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
+  uint32_t carry = 0;
+  int16_t* out = dig + (size_t)i * Pp + p;
+  const size_t plane = (size_t)N * Pp;
+#pragma unroll 1
+  for (uint32_t j = 0; j < W; j++) {
+    const uint32_t d = (l[0] & mask) + carry;
+    SPP_UNROLL for (int k = 0; k < 7; k++) l[k] = (l[k] >> c) | (l[k + 1] << (32 - c));
+    l[7] >>= c;
+    const bool over = neg ? d > half : d >= half;
+    int v = over ? (int)d - (int)(1u << c) : (int)d;
+    carry = over ? 1u : 0u;
+    if (neg) v = -v;
+    out[(size_t)j * plane] = (int16_t)v;
+  }
+}
+void launch_msm_digits(hipStream_t st, const uint32_t* rows, const Fr* scalars, int16_t* dig, uint32_t N, uint32_t P, uint32_t c) {
+  if (N == 0 || P == 0) return;
+  const uint32_t Pp = P >= 64 ? (P + 63) / 64 * 64 : P;
+  const uint64_t lanes = (uint64_t)N * Pp;
+  hipLaunchKernelGGL(k_msm_digits, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, st, rows, scalars, dig, N, P, Pp, c, msm_windows(c));
+}
+size_t msm_digit_elems(uint32_t N, uint32_t P, uint32_t c) {
+  const size_t Pp = P >= 64 ? (size_t)(P + 63) / 64 * 64 : P;
+  return (size_t)msm_windows(c) * N * Pp;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// MSM accumulate over the digit planes.
+//
+// Window passes.  A base carries Wt table rows; row m holds the multiples (d+1) * 2^(c*R*m) * Base with R = ceil(W / Wt).
+// Pass rho (0 <= rho < R) adds up  T[i][m][digit_{rho + R*m}]  over every base and row: sum_rho.  The MSM is
+// sum_rho 2^(c*rho) * sum_rho, put together per proof by k_msm_horner (c doublings per pass, once per proof and set, not per
+// base).  Wt = W (R = 1) is the classic layout, every window its own row -- small tables (8-bit windows) for the one-proof
+// latency path, no Horner step.  Wt = 1 (R = W) is the throughput layout chosen under the HBM budget: ONE row of 2^(c-1)
+// multiples per base, so for the same bytes the window is log2(W) bits wider than with a row per window -- 16-bit windows
+// (16 additions per full-size scalar) where the classic layout affords 11-12 bits (22-24 additions).
+//
+// Lane g -> (t = g / Pp, p = g % Pp), t -> (pass rho = t / Sg, slice t % Sg); Pp = P rounded up to 64 so that a wave never
+// straddles two slices (batches below 64 proofs keep Pp = P: there every lane is its own (slice, proof) anyway).  All
+// lanes of a wave walk the same (base, window) sequence: digit loads are one coalesced 128 B row, a (base, window) in which
+// every proof of the wave has a zero digit (bits, bytes, small signed noise -- most of the audit witness above window 0)
+// is skipped for the whole wave.
 // ----------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool words_all_zero(const Fq& v) {
   uint32_t o = 0;
@@ -206,92 +276,138 @@ struct MsmAcc<Fq2> {
   __device__ __forceinline__ XYZZ<Fq2> result() const { return a.to_xyzz(); }
 };
 
+
+// throughput layout (Wt = 1): one table row per base, slice sl takes bases sl, sl + Sg, ... (neighbouring wires have similar
+// scalar sizes -- runs of bits, runs of hash states -- so a strided split gives every slice the same mix).  The digits of
+// four bases are fetched ahead of their additions (2 B each, packed into one register pair).
 template <class F>
-__global__ void __launch_bounds__(256) k_msm_fixed(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ rows,
-                                                   const Fr* __restrict__ scalars, XYZZ<F>* __restrict__ partial, uint32_t N,
-                                                   uint32_t P, uint32_t c, uint32_t Wn, uint32_t S) {
+__global__ void __launch_bounds__(256) k_msm_flat(const Affine<F>* __restrict__ table, const int16_t* __restrict__ dig,
+                                                  XYZZ<F>* __restrict__ partial, uint32_t N, uint32_t P, uint32_t Pp, uint32_t c,
+                                                  uint32_t R, uint32_t Sg) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= S * P) return;
-  const uint32_t p = g % P, slice = g / P;
+  const uint32_t p = g % Pp, t = g / Pp;
+  if (t >= R * Sg || p >= P) return;
+  const uint32_t rho = t / Sg, sl = t % Sg;
   const uint32_t E = 1u << (c - 1);
-  // slice s takes bases s, s+S, s+2S, ...: neighbouring wires have similar scalar sizes (runs of bits, runs of hash
-  // states), so a strided split gives every slice the same mix and the launch no tail of heavy slices
+  const int16_t* __restrict__ dg = dig + ((size_t)rho * N) * Pp + p;
   MsmAcc<F> acc;
   acc.init();
-  for (uint32_t i = slice; i < N; i += S) {
-    Fr s = scalars[(size_t)rows[i] * P + p];
-    if (s.is_zero()) continue;
-    Recoder rc;
-    rc.init(s);
-    uint32_t row = i * Wn;
+  for (uint32_t i0 = sl; i0 < N; i0 += 4 * Sg) {
+    uint64_t pack = 0;
+    SPP_UNROLL for (uint32_t k = 0; k < 4; k++) {
+      const uint32_t i = i0 + k * Sg;
+      const uint32_t d = i < N ? (uint32_t)(uint16_t)dg[(size_t)i * Pp] : 0u;
+      pack |= (uint64_t)d << (16 * k);
+    }
+    if (pack == 0) continue;
 #pragma unroll 1
-    for (uint32_t j = 0; j < Wn; j++, row++) {
-      if (rc.rest_is_zero()) break;
-      bool sgn;
-      uint32_t d = rc.next(c, sgn);
+    for (uint32_t k = 0; k < 4; k++) {
+      const int d = (int)(int16_t)(uint16_t)(pack >> (16 * k));
       if (d != 0) {
-        acc.madd(table[((size_t)(row >> 6) * E + (d - 1)) * 64 + (row & 63)], sgn);
+        const uint32_t i = i0 + k * Sg;
+        const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+        acc.madd(table[((size_t)(i >> 6) * E + (mag - 1)) * 64 + (i & 63)], d < 0);
       }
     }
   }
-  partial[(size_t)slice * P + p] = acc.result();
+  partial[(size_t)t * P + p] = acc.result();
 }
 
-// Small batches (a single proof is the drop-in generateProof case): with one slice per 4 bases a lane walks 4 x Wn windows one
-// after the other -- 128 dependent additions, 0.7 ms per set for one withdraw proof on 32 of the chip's 1024 SIMDs.  Here the work
-// item is (base, chunk of Wq windows): Q = ceil(Wn / Wq) items per base, lane g -> (slice, proof), slice walks items slice,
-// slice + S, ...  The recoder still runs from window 0 (the signed digits carry upwards), a few shifts per skipped window.
+// general layout (Wt rows per base; Q > 1: the rows of a base are shared by Q lanes, items = (base, chunk of Wq rows) in
+// chunk-major order so that the lanes of a wave share the chunk)
 template <class F>
-__global__ void __launch_bounds__(256) k_msm_fixed_split(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ rows,
-                                                         const Fr* __restrict__ scalars, XYZZ<F>* __restrict__ partial, uint32_t N,
-                                                         uint32_t P, uint32_t c, uint32_t Wn, uint32_t S, uint32_t Q, uint32_t Wq) {
+__global__ void __launch_bounds__(256) k_msm_rows(const Affine<F>* __restrict__ table, const int16_t* __restrict__ dig,
+                                                  XYZZ<F>* __restrict__ partial, uint32_t N, uint32_t P, uint32_t Pp, uint32_t c,
+                                                  uint32_t Wt, uint32_t R, uint32_t W, uint32_t Sg, uint32_t Q, uint32_t Wq) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= S * P) return;
-  const uint32_t p = g % P, slice = g / P;
+  const uint32_t p = g % Pp, t = g / Pp;
+  if (t >= R * Sg || p >= P) return;
+  const uint32_t rho = t / Sg, sl = t % Sg;
   const uint32_t E = 1u << (c - 1);
+  const size_t plane = (size_t)N * Pp;
   MsmAcc<F> acc;
   acc.init();
   const uint32_t items = N * Q;
-  for (uint32_t t = slice; t < items; t += S) {
-    const uint32_t i = t % N, q = t / N;   // chunk-major: the lanes of a wave share q (same skip length, same add phase)
-    Fr s = scalars[(size_t)rows[i] * P + p];
-    if (s.is_zero()) continue;
-    Recoder rc;
-    rc.init(s);
-    const uint32_t j0 = q * Wq, j1 = j0 + Wq < Wn ? j0 + Wq : Wn;
-    // skip phase apart from the add phase: the lanes of a wave hold different chunks q, and an addition inside a loop
-    // whose trip count differs per lane would be executed once per distinct j (a few live lanes each time)
-    bool sgn;
+  for (uint32_t it = sl; it < items; it += Sg) {
+    uint32_t i = it, q = 0;
+    if (Q > 1) {
+      i = it % N;
+      q = it / N;
+    }
+    const uint32_t m0 = q * Wq, m1 = m0 + Wq < Wt ? m0 + Wq : Wt;
+    const int16_t* __restrict__ dg = dig + (size_t)i * Pp + p;
 #pragma unroll 1
-    for (uint32_t j = 0; j < j0; j++) (void)rc.next(c, sgn);
-#pragma unroll 1
-    for (uint32_t j = j0; j < j1; j++) {
-      if (rc.rest_is_zero()) break;
-      uint32_t d = rc.next(c, sgn);
+    for (uint32_t m = m0; m < m1; m++) {
+      const uint32_t j = rho + R * m;
+      if (j >= W) break;
+      const int d = dg[(size_t)j * plane];
       if (d != 0) {
-        const uint32_t row = i * Wn + j;
-        acc.madd(table[((size_t)(row >> 6) * E + (d - 1)) * 64 + (row & 63)], sgn);
+        const uint32_t row = i * Wt + m;
+        const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+        acc.madd(table[((size_t)(row >> 6) * E + (mag - 1)) * 64 + (row & 63)], d < 0);
       }
     }
   }
-  partial[(size_t)slice * P + p] = acc.result();
+  partial[(size_t)t * P + p] = acc.result();
 }
 
-// fold the S partial sums of every proof: pairwise, one launch per level, every lane busy -- lane (s, p) with s < S_cur - half
-// adds partial[s + half][p] into partial[s][p] (half = ceil(S_cur / 2)); log2(S) launches of S*P/2, S*P/4, ... lanes.  (The
-// first version used one 64-lane block per proof with an LDS tree: most lanes idle, six dependent additions behind barriers;
-// it cost 1.9 ms per G1 set and 10.7 ms for the G2 set on a 4096-proof batch, 12 % of a step.)
+// ev_start / ev_stop (optional): receive the dispatch's own start and stop timestamps (hipExtLaunchKernelGGL), i.e. the
+// kernel's duration as a profiler reports it -- an event pair recorded around the launch would also count the time the
+// launch waits for kernels of the other proving stream.
 template <class F>
-__global__ void __launch_bounds__(64) k_msm_fold(XYZZ<F>* __restrict__ partial, XYZZ<F>* __restrict__ out, uint32_t P, uint32_t half,
-                                                 uint32_t S_cur) {
+void launch_msm_accumulate(hipStream_t st, const Affine<F>* table, const int16_t* dig, XYZZ<F>* partial, uint32_t N, uint32_t P, uint32_t c,
+                           const MsmPlan& pl, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  if (N == 0 || P == 0) {
+    if (ev_start) hipEventRecord(ev_start, st);
+    if (ev_stop) hipEventRecord(ev_stop, st);
+    return;
+  }
+  const uint64_t lanes = (uint64_t)pl.R * pl.Sg * pl.Pp;
+  const dim3 grid((uint32_t)((lanes + 255) / 256));
+  if (pl.Wt == 1)
+    hipExtLaunchKernelGGL(k_msm_flat<F>, grid, dim3(256), 0, st, ev_start, ev_stop, 0, table, dig, partial, N, P, pl.Pp, c, pl.R, pl.Sg);
+  else
+    hipExtLaunchKernelGGL(k_msm_rows<F>, grid, dim3(256), 0, st, ev_start, ev_stop, 0, table, dig, partial, N, P, pl.Pp, c, pl.Wt, pl.R,
+                          pl.W, pl.Sg, pl.Q, pl.Wq);
+}
+
+// Fold the Sg slice sums of every (set, pass, proof): pairwise, one launch per level, every lane busy -- lane (s, p) with
+// s < S_cur - half adds partial[s + half][p] into partial[s][p] (half = ceil(S_cur / 2)).  blockIdx.y = set, blockIdx.z =
+// pass; up to MSM_FOLD_SETS sets share the launches (the five G1 sums of a proof are independent: one launch per level for
+// all of them instead of one per level and set takes most of the ~9 us launches off a single proof).  A set with one pass
+// leaves the fold in out[p]; with R > 1 passes the pass sums stay in partial[rho * Sg * P + p] for k_msm_horner.
+template <class F>
+__global__ void __launch_bounds__(64) k_msm_fold_multi(MsmFoldSets<F> fs, uint32_t P) {
+  const uint32_t set = blockIdx.y, rho = blockIdx.z;
+  const uint32_t half = fs.half[set], S_cur = fs.cur[set];
+  if (half == 0 || rho >= fs.R[set]) return;   // this set is already folded / has fewer passes
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t pairs = S_cur - half;
   if (g >= half * P) return;
+  XYZZ<F>* __restrict__ partial = fs.partial[set] + (size_t)rho * fs.Sg[set] * P;
   const uint32_t s = g / P, p = g % P;
   XYZZ<F> a = partial[(size_t)s * P + p];
   if (s < pairs) a.add(partial[(size_t)(s + half) * P + p]);
-  if (half == 1) out[p] = a;                       // last level: the result leaves the scratch array
+  if (half == 1 && fs.R[set] == 1) fs.out[set][p] = a;   // last level of a one-pass set: the result leaves the scratch array
   else if (s < pairs) partial[(size_t)s * P + p] = a;
+}
+// out[p] = sum_rho 2^(c*rho) * pass_sum[rho][p]  (Horner from the top pass down; one lane per (set, proof))
+template <class F>
+__global__ void __launch_bounds__(64) k_msm_horner(MsmFoldSets<F> fs, uint32_t P) {
+  const uint32_t set = blockIdx.y;
+  const uint32_t R = fs.R[set], c = fs.c[set];
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (R <= 1 || p >= P) return;
+  const size_t stride = (size_t)fs.Sg[set] * P;
+  const XYZZ<F>* __restrict__ sums = fs.partial[set];
+  XYZZ<F> acc = sums[(size_t)(R - 1) * stride + p];
+#pragma unroll 1
+  for (uint32_t rho = R - 1; rho-- > 0;) {
+#pragma unroll 1
+    for (uint32_t k = 0; k < c; k++) acc.dbl_inplace();
+    acc.add(sums[(size_t)rho * stride + p]);
+  }
+  fs.out[set][p] = acc;
 }
 template <class F>
 __global__ void __launch_bounds__(256) k_msm_fill_inf(XYZZ<F>* __restrict__ out, uint32_t P) {
@@ -299,71 +415,26 @@ __global__ void __launch_bounds__(256) k_msm_fill_inf(XYZZ<F>* __restrict__ out,
   if (g < P) out[g] = XYZZ<F>::infinity();
 }
 
-// ev_start / ev_stop (optional): receive the dispatch's own start and stop timestamps (hipExtLaunchKernelGGL), i.e. the
-// kernel's duration as a profiler reports it -- an event pair recorded around the launch would also count the time the
-// launch waits for kernels of the other proving stream.
+// fs: partial / out / Sg / R / c filled by the caller per set (Sg = 0: empty set, out = infinity)
 template <class F>
-void launch_msm_accumulate(hipStream_t st, const Affine<F>* table, const uint32_t* rows, const Fr* scalars, XYZZ<F>* partial, uint32_t N,
-                           uint32_t P, uint32_t c, uint32_t S, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t Q) {
-  if (N == 0 || S == 0) {
-    if (ev_start) hipEventRecord(ev_start, st);
-    if (ev_stop) hipEventRecord(ev_stop, st);
-    return;
-  }
-  uint64_t lanes = (uint64_t)S * P;
-  if (Q > 1) {
-    const uint32_t Wn = msm_windows(c);
-    hipExtLaunchKernelGGL(k_msm_fixed_split<F>, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, st, ev_start, ev_stop, 0, table, rows,
-                          scalars, partial, N, P, c, Wn, S, Q, (Wn + Q - 1) / Q);
-    return;
-  }
-  hipExtLaunchKernelGGL(k_msm_fixed<F>, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, st, ev_start, ev_stop, 0, table, rows, scalars,
-                        partial, N, P, c, msm_windows(c), S);
-}
-template <class F>
-void launch_msm_reduce(hipStream_t st, XYZZ<F>* partial, XYZZ<F>* out, uint32_t P, uint32_t S) {
-  if (P == 0) return;
-  if (S == 0) {
-    hipLaunchKernelGGL(k_msm_fill_inf<F>, dim3((P + 255) / 256), dim3(256), 0, st, out, P);
-    return;
-  }
-  uint32_t cur = S;
-  do {
-    const uint32_t half = (cur + 1) / 2;
-    const uint64_t lanes = (uint64_t)half * P;
-    hipLaunchKernelGGL(k_msm_fold<F>, dim3((uint32_t)((lanes + 63) / 64)), dim3(64), 0, st, partial, out, P, half, cur);
-    cur = half;
-  } while (cur > 1);
-}
-// the same fold for up to MSM_FOLD_SETS sets at once (blockIdx.y = set): the five G1 sums of a proof are independent, and one
-// launch per level for all of them instead of one per level and set takes 64 of the 80 ~9 us launches off a single proof
-template <class F>
-__global__ void __launch_bounds__(64) k_msm_fold_multi(MsmFoldSets<F> fs, uint32_t P) {
-  const uint32_t set = blockIdx.y;
-  const uint32_t half = fs.half[set], S_cur = fs.cur[set];
-  if (half == 0) return;   // this set is already folded
-  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t pairs = S_cur - half;
-  if (g >= half * P) return;
-  XYZZ<F>* __restrict__ partial = fs.partial[set];
-  const uint32_t s = g / P, p = g % P;
-  XYZZ<F> a = partial[(size_t)s * P + p];
-  if (s < pairs) a.add(partial[(size_t)(s + half) * P + p]);
-  if (half == 1) fs.out[set][p] = a;
-  else if (s < pairs) partial[(size_t)s * P + p] = a;
-}
-template <class F>
-void launch_msm_reduce_multi(hipStream_t st, MsmFoldSets<F> fs, uint32_t nsets, const uint32_t* S, uint32_t P) {
+void launch_msm_reduce_multi(hipStream_t st, MsmFoldSets<F> fs, uint32_t nsets, uint32_t P) {
   if (P == 0 || nsets == 0) return;
   uint32_t cur[MSM_FOLD_SETS];
   bool done[MSM_FOLD_SETS];
+  uint32_t maxR = 1;
+  bool horner = false;
   for (uint32_t i = 0; i < nsets; i++) {
-    cur[i] = S[i];
+    cur[i] = fs.Sg[i];
     done[i] = false;
-    if (S[i] == 0) {
+    if (fs.Sg[i] == 0) {
       hipLaunchKernelGGL(k_msm_fill_inf<F>, dim3((P + 255) / 256), dim3(256), 0, st, fs.out[i], P);
       done[i] = true;
+      fs.R[i] = 1;
+      continue;
     }
+    if (fs.R[i] > 1) horner = true;
+    if (fs.R[i] > 1 && fs.Sg[i] == 1) done[i] = true;   // nothing to fold: the pass sums are already in place
+    maxR = std::max(maxR, fs.R[i]);
   }
   for (;;) {
     uint64_t lanes = 0;
@@ -373,21 +444,37 @@ void launch_msm_reduce_multi(hipStream_t st, MsmFoldSets<F> fs, uint32_t nsets, 
       lanes = std::max<uint64_t>(lanes, (uint64_t)fs.half[i] * P);
     }
     if (lanes == 0) break;
-    hipLaunchKernelGGL(k_msm_fold_multi<F>, dim3((uint32_t)((lanes + 63) / 64), nsets), dim3(64), 0, st, fs, P);
+    hipLaunchKernelGGL(k_msm_fold_multi<F>, dim3((uint32_t)((lanes + 63) / 64), nsets, maxR), dim3(64), 0, st, fs, P);
     for (uint32_t i = 0; i < nsets; i++)
       if (!done[i]) {
         cur[i] = fs.half[i];
         if (cur[i] == 1) done[i] = true;
       }
   }
+  if (horner) {
+    for (uint32_t i = 0; i < nsets; i++)
+      if (fs.Sg[i] == 0) fs.R[i] = 1;
+    hipLaunchKernelGGL(k_msm_horner<F>, dim3((P + 63) / 64, nsets), dim3(64), 0, st, fs, P);
+  }
 }
-template void launch_msm_reduce_multi<Fq>(hipStream_t, MsmFoldSets<Fq>, uint32_t, const uint32_t*, uint32_t);
-template void launch_msm_accumulate<Fq>(hipStream_t, const Affine<Fq>*, const uint32_t*, const Fr*, XYZZ<Fq>*, uint32_t, uint32_t, uint32_t,
-                                        uint32_t, hipEvent_t, hipEvent_t, uint32_t);
-template void launch_msm_accumulate<Fq2>(hipStream_t, const Affine<Fq2>*, const uint32_t*, const Fr*, XYZZ<Fq2>*, uint32_t, uint32_t,
-                                         uint32_t, uint32_t, hipEvent_t, hipEvent_t, uint32_t);
-template void launch_msm_reduce<Fq>(hipStream_t, XYZZ<Fq>*, XYZZ<Fq>*, uint32_t, uint32_t);
-template void launch_msm_reduce<Fq2>(hipStream_t, XYZZ<Fq2>*, XYZZ<Fq2>*, uint32_t, uint32_t);
+template <class F>
+void launch_msm_reduce(hipStream_t st, XYZZ<F>* partial, XYZZ<F>* out, uint32_t P, const MsmPlan& pl, uint32_t c, bool empty) {
+  MsmFoldSets<F> fs{};
+  fs.partial[0] = partial;
+  fs.out[0] = out;
+  fs.Sg[0] = empty ? 0 : pl.Sg;
+  fs.R[0] = pl.R;
+  fs.c[0] = c;
+  launch_msm_reduce_multi<F>(st, fs, 1, P);
+}
+template void launch_msm_reduce_multi<Fq>(hipStream_t, MsmFoldSets<Fq>, uint32_t, uint32_t);
+template void launch_msm_reduce_multi<Fq2>(hipStream_t, MsmFoldSets<Fq2>, uint32_t, uint32_t);
+template void launch_msm_accumulate<Fq>(hipStream_t, const Affine<Fq>*, const int16_t*, XYZZ<Fq>*, uint32_t, uint32_t, uint32_t, const MsmPlan&,
+                                        hipEvent_t, hipEvent_t);
+template void launch_msm_accumulate<Fq2>(hipStream_t, const Affine<Fq2>*, const int16_t*, XYZZ<Fq2>*, uint32_t, uint32_t, uint32_t,
+                                         const MsmPlan&, hipEvent_t, hipEvent_t);
+template void launch_msm_reduce<Fq>(hipStream_t, XYZZ<Fq>*, XYZZ<Fq>*, uint32_t, const MsmPlan&, uint32_t, bool);
+template void launch_msm_reduce<Fq2>(hipStream_t, XYZZ<Fq2>*, XYZZ<Fq2>*, uint32_t, const MsmPlan&, uint32_t, bool);
 
 // ----------------------------------------------------------------------------------------------------
 // setup: out[i] = scalars[i] * G using the window table of the single base G

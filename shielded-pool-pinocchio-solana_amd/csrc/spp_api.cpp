@@ -15,12 +15,14 @@ struct MsmSet {
   uint32_t* rows = nullptr;
   bool from_h = false;   // scalars come from the h array instead of the witness
   uint32_t c = 0;        // window bits of this set's table
+  uint32_t Wt = 0;       // table rows per base: msm_windows(c) = one per window (no passes), 1 = one row and msm_windows(c) passes
 };
 template <class F>
 struct MsmBuf {
   XYZZ<F>* partial = nullptr;
   XYZZ<F>* out = nullptr;
   size_t partial_cap = 0;   // elements allocated in `partial`
+  MsmPlan plan{};           // lane layout of the last launch (the fold needs it)
 };
 struct Workspace {
   hipStream_t st = nullptr;
@@ -39,6 +41,10 @@ struct Workspace {
   MsmBuf<Fq> sA, rB;                  // small batches: s*Ar and r*Bs1 as table sums over the scaled witness (Ws, Wr)
   Fr *Ws = nullptr, *Wr = nullptr;
   MsmBuf<Fq2> B2;
+  // signed-digit planes of the scalars of one MSM (kernels_msm.hip): dig1 is shared by the G1 sets, which run one after the
+  // other on `st`; the G2 set runs beside them on the side stream and has its own
+  int16_t *dig1 = nullptr, *dig2 = nullptr;
+  size_t dig1_cap = 0, dig2_cap = 0;
   std::vector<void*> owned;
   hipEvent_t ev[8] = {};
   std::vector<std::pair<hipEvent_t, hipEvent_t>> msm_ev;
@@ -49,7 +55,7 @@ template <class F>
 struct PendingTable {
   std::vector<Affine<F>> pts;
   Affine<F>* table;
-  uint32_t c;
+  uint32_t c, Wt;
 };
 struct SolveStep {
   enum Kind { SEQ, BATCH_DIV, COUNT8, COMMIT } kind;
@@ -504,8 +510,8 @@ static int upload_sparse(spp_circuit* c, const Circuit& circ, const Sparse& m, D
 // window tables: allocate first (all sets), then build with temporaries sized from the HBM that is left, so that
 // each launch has enough rows (>= tens of thousands of lanes) to fill the chip
 template <class F>
-static int alloc_table(spp_circuit* c, size_t N, uint32_t cbits, Affine<F>** table_out) {
-  size_t table_elems = std::max<size_t>(msm_table_elems((uint32_t)N, cbits), 1);
+static int alloc_table(spp_circuit* c, size_t N, uint32_t cbits, uint32_t Wt, Affine<F>** table_out) {
+  size_t table_elems = std::max<size_t>(msm_table_elems((uint32_t)N, cbits, Wt), 1);
   Affine<F>* table;
   HIP_TRY(hipMalloc((void**)&table, table_elems * sizeof(Affine<F>)));
   c->owned.push_back(table);
@@ -514,9 +520,9 @@ static int alloc_table(spp_circuit* c, size_t N, uint32_t cbits, Affine<F>** tab
   return 0;
 }
 template <class F>
-static int build_table(spp_circuit* c, const std::vector<Affine<F>>& pts, uint32_t cbits, Affine<F>* table, size_t temp_budget) {
+static int build_table(spp_circuit* c, const std::vector<Affine<F>>& pts, uint32_t cbits, uint32_t Wt, Affine<F>* table, size_t temp_budget) {
   hipStream_t st = c->ctx->stream;
-  const uint32_t Wn = msm_windows(cbits), E = 1u << (cbits - 1);
+  const uint32_t Wn = Wt, E = 1u << (cbits - 1);
   const size_t N = pts.size();
   if (N == 0) return 0;
   const size_t rows_total = ((N * Wn + 63) / 64) * 64;
@@ -531,7 +537,7 @@ static int build_table(spp_circuit* c, const std::vector<Affine<F>>& pts, uint32
   HIP_TRY(tmp_pre.alloc(chunk * E * sizeof(F)));
   for (size_t r0 = 0; r0 < rows_total; r0 += chunk) {
     uint32_t cnt = (uint32_t)std::min(chunk, rows_total - r0);
-    launch_build_table<F>(st, d_bases.as<Affine<F>>(), (uint32_t)N, cbits, (uint32_t)r0, cnt, table, tmp.as<XYZZ<F>>(), tmp_pre.as<F>());
+    launch_build_table<F>(st, d_bases.as<Affine<F>>(), (uint32_t)N, cbits, Wt, (uint32_t)r0, cnt, table, tmp.as<XYZZ<F>>(), tmp_pre.as<F>());
   }
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipGetLastError());
@@ -545,28 +551,29 @@ static size_t table_temp_budget() {
   return std::max(b, (size_t)1 << 28);
 }
 template <class F>
-static int build_table_chunked(spp_circuit* c, const std::vector<Affine<F>>& pts, uint32_t cbits, Affine<F>** table_out) {
-  if (int e = alloc_table<F>(c, pts.size(), cbits, table_out)) return e;
-  return build_table<F>(c, pts, cbits, *table_out, std::min(table_temp_budget(), (size_t)2 << 30));
+static int build_table_chunked(spp_circuit* c, const std::vector<Affine<F>>& pts, uint32_t cbits, uint32_t Wt, Affine<F>** table_out) {
+  if (int e = alloc_table<F>(c, pts.size(), cbits, Wt, table_out)) return e;
+  return build_table<F>(c, pts, cbits, Wt, *table_out, std::min(table_temp_budget(), (size_t)2 << 30));
 }
 
 
 template <class F>
 static int make_set(spp_circuit* c, MsmSet<F>* set, const std::vector<uint32_t>& rows, const std::vector<Affine<F>>& pts, bool from_h,
-                    uint32_t cbits) {
+                    uint32_t cbits, bool flat) {
   set->N = (uint32_t)pts.size();
   set->from_h = from_h;
   set->c = cbits;
+  set->Wt = flat ? 1 : msm_windows(cbits);
   if (int e = own_upload(c, &set->rows, rows)) return e;
-  if (int e = alloc_table<F>(c, pts.size(), cbits, &set->table)) return e;
-  pending(c, (F*)nullptr).push_back({pts, set->table, cbits});
+  if (int e = alloc_table<F>(c, pts.size(), cbits, set->Wt, &set->table)) return e;
+  pending(c, (F*)nullptr).push_back({pts, set->table, cbits, set->Wt});
   return 0;
 }
 static int build_pending(spp_circuit* c) {
   const size_t budget = table_temp_budget();
   int e = 0;
-  for (auto& p : pending(c, (Fq*)nullptr)) if (!e) e = build_table<Fq>(c, p.pts, p.c, p.table, budget);
-  for (auto& p : pending(c, (Fq2*)nullptr)) if (!e) e = build_table<Fq2>(c, p.pts, p.c, p.table, budget);
+  for (auto& p : pending(c, (Fq*)nullptr)) if (!e) e = build_table<Fq>(c, p.pts, p.c, p.Wt, p.table, budget);
+  for (auto& p : pending(c, (Fq2*)nullptr)) if (!e) e = build_table<Fq2>(c, p.pts, p.c, p.Wt, p.table, budget);
   pending(c, (Fq*)nullptr).clear();
   pending(c, (Fq2*)nullptr).clear();
   return e;
@@ -776,24 +783,37 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
   const Circuit& circ = c->circ;
   if (pk.circuit_id != circ.id || pk.n_wires != circ.n_wires || pk.domain_log != circ.domain_log)
     return fail(SPP_ERR_FORMAT, "proving key does not match the circuit");
-  // window bits per MSM set: uniform when requested, otherwise a greedy split of the HBM budget (env
-  // SPP_TABLE_BUDGET_GB, default 240 of the 288 GB, capped at 85 % of the free HBM): repeatedly widen the set whose next window bit
-  // removes the most mixed-addition work per extra byte (one bit ~ -8 % additions, x2 table; a G2 addition is
-  // weighted 3 G1 additions, as measured).  The two commitment sets only ever see bytes / small counters: fixed 9-bit windows.
+  // Window bits and table layout per MSM set.
+  //  * window_bits given: every set gets one table row per window (msm_windows(c) rows of 2^(c-1) multiples per base) -- small
+  //    tables, a single pass, no Horner step: the layout of the one-proof latency path (the drop-in helpers load 8 bits).
+  //  * window_bits = 0 (throughput): the five big sets keep ONE row per base and walk it once per window ("flat", see
+  //    kernels_msm.hip); the window of every set is a greedy split of the HBM budget (env SPP_TABLE_BUDGET_GB, default 240 of the
+  //    288 GB, capped at 85 % of the free HBM): repeatedly widen the set whose next window bit removes the most mixed-addition
+  //    work per extra byte (a G2 addition is weighted 3 G1 additions, as measured).  A flat G1 row at 16 bits is 2 MB per base
+  //    and costs 16 additions per full-size scalar; the row-per-window layout of rounds 1-2 afforded 11-12 bits (22-24
+  //    additions) in the same bytes (SPP_FLAT=0 brings it back for comparison).  The two commitment sets only ever see bytes /
+  //    small counters and sit on the critical path of the challenge: row-per-window tables at 9 bits, no passes.
   uint32_t cw[7];   // A, B1, K, Z, CB, CS, B2
+  bool flat[7] = {false, false, false, false, false, false, false};
   {
     const double nset[7] = {(double)pk.A.size() + 2, (double)pk.B1.size() + 2, (double)pk.K.size() + 1, (double)pk.Z.size(),
                             (double)pk.CB.size(), (double)pk.CS.size(), (double)pk.B2.size() + 2};
     const double esz[7] = {64, 64, 64, 64, 64, 64, 128}, wgt[7] = {1, 1, 1, 1, 0, 0, 3.0};
-    auto bytes = [&](int s, int cb) { return nset[s] * esz[s] * msm_windows((uint32_t)cb) * (double)(1u << (cb - 1)); };
     if (window_bits != 0) {
       for (int s = 0; s < 7; s++) cw[s] = (uint32_t)window_bits;
     } else {
+      const char* fe = getenv("SPP_FLAT");
+      const bool use_flat = !(fe && fe[0] == '0');
+      for (int s = 0; s < 7; s++) flat[s] = use_flat && wgt[s] != 0;
+      auto bytes = [&](int s, int cb) {
+        return nset[s] * esz[s] * (flat[s] ? 1.0 : (double)msm_windows((uint32_t)cb)) * (double)(1u << (cb - 1));
+      };
       size_t free_b = 0, total_b = 0;
       HIP_TRY(hipMemGetInfo(&free_b, &total_b));
       double budget = 240e9;
       if (const char* env = getenv("SPP_TABLE_BUDGET_GB")) budget = atof(env) * 1e9;
       budget = std::min(budget, 0.85 * (double)free_b);
+      const int cmax = use_flat ? 16 : 15;
       int cur[7] = {6, 6, 6, 6, 9, 9, 6};
       double used = 0;
       for (int s = 0; s < 7; s++) used += bytes(s, cur[s]);
@@ -801,7 +821,7 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
         int best = -1;
         double best_gain = 0;
         for (int s = 0; s < 7; s++) {
-          if (wgt[s] == 0 || cur[s] >= 15) continue;
+          if (wgt[s] == 0 || cur[s] >= cmax) continue;
           double extra = bytes(s, cur[s] + 1) - bytes(s, cur[s]);
           if (used + extra > budget) continue;
           double saved = wgt[s] * nset[s] * ((double)msm_windows((uint32_t)cur[s]) - (double)msm_windows((uint32_t)cur[s] + 1));
@@ -813,6 +833,9 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
         used += bytes(best, cur[best] + 1) - bytes(best, cur[best]);
         cur[best]++;
       }
+      // a last bit that did not lower the window count buys nothing: give it back (14 -> 13 never happens: 19 < 20 windows)
+      for (int s = 0; s < 7; s++)
+        while (wgt[s] != 0 && cur[s] > 6 && msm_windows((uint32_t)cur[s]) == msm_windows((uint32_t)cur[s] - 1)) cur[s]--;
       for (int s = 0; s < 7; s++) cw[s] = (uint32_t)cur[s];
     }
     c->c_bits = cw[3];   // reported window = that of the largest set (Z)
@@ -1013,27 +1036,27 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
     std::vector<G1Affine> p = pk.A;
     merge_point(w, p, 0u, pk.alpha1);
     w.push_back(c->row_r); p.push_back(pk.delta1);
-    if ((e = make_set(c, &c->A, w, p, false, cw[0]))) return e;
+    if ((e = make_set(c, &c->A, w, p, false, cw[0], flat[0]))) return e;
   }
   {
     std::vector<uint32_t> w = pk.B1_w;
     std::vector<G1Affine> p = pk.B1;
     merge_point(w, p, 0u, pk.beta1);
     w.push_back(c->row_s); p.push_back(pk.delta1);
-    if ((e = make_set(c, &c->B1, w, p, false, cw[1]))) return e;
+    if ((e = make_set(c, &c->B1, w, p, false, cw[1], flat[1]))) return e;
   }
   {
     std::vector<uint32_t> w = pk.B2_w;
     std::vector<G2Affine> p = pk.B2;
     merge_point(w, p, 0u, pk.beta2);
     w.push_back(c->row_s); p.push_back(pk.delta2);
-    if ((e = make_set(c, &c->B2, w, p, false, cw[6]))) return e;
+    if ((e = make_set(c, &c->B2, w, p, false, cw[6], flat[6]))) return e;
   }
   {
     std::vector<uint32_t> w = pk.K_w;
     std::vector<G1Affine> p = pk.K;
     w.push_back(c->row_rs); p.push_back(pk.delta1.neg());
-    if ((e = make_set(c, &c->K, w, p, false, cw[2]))) return e;
+    if ((e = make_set(c, &c->K, w, p, false, cw[2], flat[2]))) return e;
   }
   {
     // h comes out of the last DIF pass in bit-reversed order: row `pos` holds h_{bitrev(pos)}
@@ -1046,10 +1069,10 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
       w.push_back(pos);
       p.push_back(pk.Z[i]);
     }
-    if ((e = make_set(c, &c->Z, w, p, true, cw[3]))) return e;
+    if ((e = make_set(c, &c->Z, w, p, true, cw[3], flat[3]))) return e;
   }
-  if ((e = make_set(c, &c->CB, pk.CB_w, pk.CB, false, cw[4]))) return e;
-  if ((e = make_set(c, &c->CS, pk.CS_w, pk.CS, false, cw[5]))) return e;
+  if ((e = make_set(c, &c->CB, pk.CB_w, pk.CB, false, cw[4], false))) return e;
+  if ((e = make_set(c, &c->CS, pk.CS_w, pk.CS, false, cw[5], false))) return e;
   if ((e = build_pending(c))) return e;
 
   for (int k = 0; k < 2; k++) {
@@ -1128,6 +1151,11 @@ extern "C" int spp_circuit_msm_windows(const spp_circuit* c, uint32_t bits[7]) {
   bits[0] = c->A.c; bits[1] = c->B1.c; bits[2] = c->K.c; bits[3] = c->Z.c; bits[4] = c->CB.c; bits[5] = c->CS.c; bits[6] = c->B2.c;
   return SPP_OK;
 }
+extern "C" int spp_circuit_msm_table_rows(const spp_circuit* c, uint32_t rows[7]) {
+  if (!c || !rows) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  rows[0] = c->A.Wt; rows[1] = c->B1.Wt; rows[2] = c->K.Wt; rows[3] = c->Z.Wt; rows[4] = c->CB.Wt; rows[5] = c->CS.Wt; rows[6] = c->B2.Wt;
+  return SPP_OK;
+}
 extern "C" int spp_circuit_msm_sizes(const spp_circuit* c, uint32_t sizes[7]) {
   if (!c || !sizes) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
   sizes[0] = c->A.N; sizes[1] = c->B1.N; sizes[2] = c->K.N; sizes[3] = c->Z.N; sizes[4] = c->CB.N; sizes[5] = c->CS.N; sizes[6] = c->B2.N;
@@ -1142,11 +1170,11 @@ static int ws_alloc(Workspace& w, T** p, size_t count) {
 }
 template <class F>
 static int ws_set(Workspace& w, const MsmSet<F>* s, MsmBuf<F>* b, size_t P) {
-  // S(P')*P' <= min(target + P', ceil(N/4)*P') for every P' <= P
-  size_t max_s = std::max<size_t>((s->N + 3) / 4, 1);
-  b->partial_cap = std::min<size_t>((size_t)256 * 4 * 4 * 64 + P, max_s * P);
-  b->partial_cap = std::max<size_t>(b->partial_cap, (size_t)msm_slices(s->N, (uint32_t)P) * P);
-  b->partial_cap = std::max<size_t>(b->partial_cap, 65536 + P);   // small batches: up to 64K (base, window chunk) lanes
+  // R * Sg(P') * P' <= lane target + R * P' for every P' <= P (msm_plan); small batches: up to 64K (item, pass) lanes
+  const uint32_t R = msm_plan(s->N, (uint32_t)P, s->c, s->Wt).R;
+  b->partial_cap = (size_t)256 * 4 * 8 * 64 + 65536 + (size_t)(R + 1) * (P + 64);
+  for (size_t q = P; q >= 1; q /= 2)   // and the exact need at the sizes most likely to be used
+    b->partial_cap = std::max(b->partial_cap, msm_plan(s->N, (uint32_t)q, s->c, s->Wt).partial_elems((uint32_t)q));
   int e;
   if ((e = ws_alloc(w, &b->partial, b->partial_cap))) return e;
   return ws_alloc(w, &b->out, P);
@@ -1173,25 +1201,37 @@ static int ensure_workspace(spp_circuit* c, Workspace& w, size_t P) {
         (e = ws_alloc(w, &w.Wr, (size_t)c->n_rows * Ps)))
       return e;
   }
+  {
+    // digit planes: the G1 sets share one buffer (they run one after the other on `st`), the G2 set has its own
+    size_t d1 = 0;
+    for (const MsmSet<Fq>* s : {&c->A, &c->B1, &c->K, &c->Z, &c->CB, &c->CS}) d1 = std::max(d1, msm_digit_elems(s->N, (uint32_t)P, s->c));
+    w.dig1_cap = d1;
+    w.dig2_cap = msm_digit_elems(c->B2.N, (uint32_t)P, c->B2.c);
+    if ((e = ws_alloc(w, &w.dig1, w.dig1_cap)) || (e = ws_alloc(w, &w.dig2, w.dig2_cap))) return e;
+  }
   w.cap = P;
   return 0;
 }
 
+static int16_t* ws_dig(Workspace& w, Fq*) { return w.dig1; }
+static int16_t* ws_dig(Workspace& w, Fq2*) { return w.dig2; }
+// digits + accumulate of one set; the caller folds (several sets share the fold launches): b.plan holds the lane layout
 template <class F>
 static void run_msm(spp_circuit* c, Workspace& w, const MsmSet<F>& s, MsmBuf<F>& b, uint32_t P, bool timed, hipStream_t st_override = nullptr,
-                    std::pair<hipEvent_t, hipEvent_t>* ev_override = nullptr, uint32_t* S_out = nullptr, const Fr* scal_override = nullptr) {
+                    std::pair<hipEvent_t, hipEvent_t>* ev_override = nullptr, bool fold = true, const Fr* scal_override = nullptr) {
   hipStream_t st = st_override ? st_override : w.st;
   const Fr* scal = scal_override ? scal_override : s.from_h ? w.abc : w.W;
-  const uint32_t Q = msm_window_chunks(s.N, P, s.c);   // > 1 for small batches: the windows of a base are shared by Q lanes
-  uint32_t S = msm_slices_split(s.N, P, Q);
-  while (S > 1 && (size_t)S * P > b.partial_cap) S--;  // never exceed the allocated partial buffer
+  MsmPlan pl = msm_plan(s.N, P, s.c, s.Wt);
+  while (pl.Sg > 1 && pl.partial_elems(P) > b.partial_cap) pl.Sg--;  // never exceed the allocated partial buffer
+  b.plan = pl;
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
   if (timed && w.msm_ev_used < w.msm_ev.size()) ev = &w.msm_ev[w.msm_ev_used++];
   if (ev_override) ev = ev_override;
+  int16_t* dig = ws_dig(w, (F*)nullptr);
+  launch_msm_digits(st, s.rows, scal, dig, s.N, P, s.c);
   // the event pair receives the dispatch's own start/stop timestamps (what rocprofv3 reports as the kernel's duration)
-  launch_msm_accumulate<F>(st, s.table, s.rows, scal, b.partial, s.N, P, s.c, S, ev ? ev->first : nullptr, ev ? ev->second : nullptr, Q);
-  if (S_out) *S_out = s.N ? S : 0;   // the caller folds several sets together
-  else launch_msm_reduce<F>(st, b.partial, b.out, P, s.N ? S : 0);
+  launch_msm_accumulate<F>(st, s.table, dig, b.partial, s.N, P, s.c, pl, ev ? ev->first : nullptr, ev ? ev->second : nullptr);
+  if (fold) launch_msm_reduce<F>(st, b.partial, b.out, P, pl, s.c, s.N == 0);
 }
 
 static int prove_on_device(spp_circuit* c, Workspace& w, uint32_t P, const uint8_t* d_inputs, const uint8_t* d_rs, uint8_t* d_proofs,
@@ -1259,18 +1299,20 @@ static int prove_on_device(spp_circuit* c, Workspace& w, uint32_t P, const uint8
   // 4. MSMs
   {
     MsmFoldSets<Fq> fs{};
-    uint32_t S[7];
     const MsmSet<Fq>* sets[7] = {&c->A, &c->B1, &c->K, &c->Z, &c->CS, &c->A, &c->B1};
     MsmBuf<Fq>* bufs[7] = {&w.A, &w.B1, &w.K, &w.Z, &w.CS, &w.sA, &w.rB};
     const Fr* scal[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, w.Ws, w.Wr};
     const int nsets = scaled_blind ? 7 : 5;
     if (scaled_blind) launch_scale_witness(st, w.W, w.Ws, w.Wr, c->n_rows, c->row_r, c->row_s, P);
     for (int i = 0; i < nsets; i++) {
-      run_msm(c, w, *sets[i], *bufs[i], P, i < 5, nullptr, nullptr, &S[i], scal[i]);
+      run_msm(c, w, *sets[i], *bufs[i], P, i < 5, nullptr, nullptr, false, scal[i]);
       fs.partial[i] = bufs[i]->partial;
       fs.out[i] = bufs[i]->out;
+      fs.Sg[i] = sets[i]->N ? bufs[i]->plan.Sg : 0;
+      fs.R[i] = bufs[i]->plan.R;
+      fs.c[i] = sets[i]->c;
     }
-    launch_msm_reduce_multi<Fq>(st, fs, nsets, S, P);   // the partial-sum arrays are folded level by level in shared launches
+    launch_msm_reduce_multi<Fq>(st, fs, nsets, P);   // the slice sums are folded level by level in shared launches, then Horner
   }
   hipEventRecord(w.ev[4], st);
   hipStreamWaitEvent(st, w.ev_b2, 0);   // join the G2 MSM
@@ -1611,7 +1653,7 @@ extern "C" int spp_setup(spp_ctx* ctx, const char* circuit_path, const uint8_t s
   DevBuf d_g1, d_g2, t1, t2, tmp1, tmp2, pre1, pre2, d_s1, d_s2, o1, o2;   // released on every return path
   HIP_TRY(d_g1.alloc(sizeof g1)); HIP_TRY(hipMemcpy(d_g1.p, &g1, sizeof g1, hipMemcpyHostToDevice));
   HIP_TRY(d_g2.alloc(sizeof g2)); HIP_TRY(hipMemcpy(d_g2.p, &g2, sizeof g2, hipMemcpyHostToDevice));
-  const size_t ge = msm_table_elems(1, cb), gr = ((size_t)Wn + 63) / 64 * 64;
+  const size_t ge = msm_table_elems(1, cb, Wn), gr = ((size_t)Wn + 63) / 64 * 64;
   HIP_TRY(t1.alloc(sizeof(G1Affine) * ge)); HIP_TRY(t2.alloc(sizeof(G2Affine) * ge));
   HIP_TRY(tmp1.alloc(sizeof(G1XYZZ) * gr * E)); HIP_TRY(tmp2.alloc(sizeof(G2XYZZ) * gr * E));
   HIP_TRY(pre1.alloc(sizeof(Fq) * gr * E)); HIP_TRY(pre2.alloc(sizeof(Fq2) * gr * E));
@@ -1619,8 +1661,8 @@ extern "C" int spp_setup(spp_ctx* ctx, const char* circuit_path, const uint8_t s
   HIP_TRY(o1.alloc(sizeof(G1Affine) * s1.size())); HIP_TRY(o2.alloc(sizeof(G2Affine) * s2.size()));
   HIP_TRY(hipMemcpyAsync(d_s1.p, s1.data(), sizeof(Fr) * s1.size(), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(d_s2.p, s2.data(), sizeof(Fr) * s2.size(), hipMemcpyHostToDevice, st));
-  launch_build_table<Fq>(st, d_g1.as<G1Affine>(), 1, cb, 0, (uint32_t)gr, t1.as<G1Affine>(), tmp1.as<G1XYZZ>(), pre1.as<Fq>());
-  launch_build_table<Fq2>(st, d_g2.as<G2Affine>(), 1, cb, 0, (uint32_t)gr, t2.as<G2Affine>(), tmp2.as<G2XYZZ>(), pre2.as<Fq2>());
+  launch_build_table<Fq>(st, d_g1.as<G1Affine>(), 1, cb, Wn, 0, (uint32_t)gr, t1.as<G1Affine>(), tmp1.as<G1XYZZ>(), pre1.as<Fq>());
+  launch_build_table<Fq2>(st, d_g2.as<G2Affine>(), 1, cb, Wn, 0, (uint32_t)gr, t2.as<G2Affine>(), tmp2.as<G2XYZZ>(), pre2.as<Fq2>());
   launch_fixed_base_mul<Fq>(st, t1.as<G1Affine>(), cb, d_s1.as<Fr>(), (uint32_t)s1.size(), o1.as<G1Affine>(), nullptr);
   launch_fixed_base_mul<Fq2>(st, t2.as<G2Affine>(), cb, d_s2.as<Fr>(), (uint32_t)s2.size(), o2.as<G2Affine>(), nullptr);
   std::vector<G1Affine> p1(s1.size());
@@ -1699,7 +1741,7 @@ static int msm_fixed_unit(spp_ctx* ctx, const uint8_t* bases, const uint8_t* sca
   hipStream_t st = ctx->stream;
   const uint32_t cb = (uint32_t)window_bits, Wn = msm_windows(cb), E = 1u << (cb - 1);
   (void)E;
-  if ((uint64_t)msm_table_elems((uint32_t)n, cb) * PT_BYTES > ((uint64_t)64 << 30)) return fail(SPP_ERR_BAD_INPUT, "table would exceed 64 GiB; use a smaller window");
+  if ((uint64_t)msm_table_elems((uint32_t)n, cb, Wn) * PT_BYTES > ((uint64_t)64 << 30)) return fail(SPP_ERR_BAD_INPUT, "table would exceed 64 GiB; use a smaller window");
   std::vector<Affine<F>> pts(n);
   std::vector<Fr> sc(n);
   std::vector<uint32_t> rows(n);
@@ -1712,19 +1754,22 @@ static int msm_fixed_unit(spp_ctx* ctx, const uint8_t* bases, const uint8_t* sca
   tmpc.ctx = ctx;
   tmpc.c_bits = cb;
   Affine<F>* table = nullptr;
-  int e = build_table_chunked<F>(&tmpc, pts, cb, &table);
+  int e = build_table_chunked<F>(&tmpc, pts, cb, Wn, &table);
   Fr* d_sc = nullptr;
   uint32_t* d_rows = nullptr;
   XYZZ<F> *partial = nullptr, *d_out = nullptr;
-  uint32_t S = msm_slices((uint32_t)n, 1);
+  DevBuf dig;
+  const MsmPlan pl = msm_plan((uint32_t)n, 1, cb, Wn);
   if (!e) e = own_upload(&tmpc, &d_sc, sc);
   if (!e) e = own_upload(&tmpc, &d_rows, rows);
-  if (!e && hipMalloc((void**)&partial, sizeof(XYZZ<F>) * S) != hipSuccess) e = fail(SPP_ERR_HIP, "hipMalloc");
+  if (!e && hipMalloc((void**)&partial, sizeof(XYZZ<F>) * std::max<size_t>(pl.partial_elems(1), 1)) != hipSuccess) e = fail(SPP_ERR_HIP, "hipMalloc");
   if (!e && hipMalloc((void**)&d_out, sizeof(XYZZ<F>)) != hipSuccess) e = fail(SPP_ERR_HIP, "hipMalloc");
+  if (!e && dig.alloc(sizeof(int16_t) * std::max<size_t>(msm_digit_elems((uint32_t)n, 1, cb), 1)) != hipSuccess) e = fail(SPP_ERR_HIP, "hipMalloc");
   XYZZ<F> res = XYZZ<F>::infinity();
   if (!e) {
-    launch_msm_accumulate<F>(st, table, d_rows, d_sc, partial, (uint32_t)n, 1, cb, S);
-    launch_msm_reduce<F>(st, partial, d_out, 1, n ? S : 0);
+    launch_msm_digits(st, d_rows, d_sc, dig.as<int16_t>(), (uint32_t)n, 1, cb);
+    launch_msm_accumulate<F>(st, table, dig.as<int16_t>(), partial, (uint32_t)n, 1, cb, pl);
+    launch_msm_reduce<F>(st, partial, d_out, 1, pl, cb, n == 0);
     if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) e = fail(SPP_ERR_HIP, "msm kernels failed");
     else if (hipMemcpy(&res, d_out, sizeof res, hipMemcpyDeviceToHost) != hipSuccess) e = fail(SPP_ERR_HIP, "copy back failed");
   }

@@ -146,10 +146,10 @@ extern "C" int spp_msm_g1_pippenger_bench_dist(spp_ctx* ctx, size_t n, uint64_t 
   G1Affine g1{Fq::from_u64(1), Fq::from_u64(2)};
   UP(dg, &g1, sizeof g1);
   const size_t gr = ((size_t)Wn + 63) / 64 * 64;
-  HIP_TRY(dt.alloc(sizeof(G1Affine) * msm_table_elems(1, cb)));
+  HIP_TRY(dt.alloc(sizeof(G1Affine) * msm_table_elems(1, cb, Wn)));
   HIP_TRY(dtmp.alloc(sizeof(G1XYZZ) * gr * E));
   HIP_TRY(dpre.alloc(sizeof(Fq) * gr * E));
-  launch_build_table<Fq>(st, dg.as<G1Affine>(), 1, cb, 0, (uint32_t)gr, dt.as<G1Affine>(), dtmp.as<G1XYZZ>(), dpre.as<Fq>());
+  launch_build_table<Fq>(st, dg.as<G1Affine>(), 1, cb, Wn, 0, (uint32_t)gr, dt.as<G1Affine>(), dtmp.as<G1XYZZ>(), dpre.as<Fq>());
   launch_fixed_base_mul<Fq>(st, dt.as<G1Affine>(), cb, dk.as<Fr>(), (uint32_t)n, dp.as<G1Affine>(), nullptr);
   HIP_TRY(hipStreamSynchronize(st));
   hipEvent_t e0, e1, k0, k1;

@@ -52,6 +52,7 @@ def load_library():
     L.spp_circuit_info.argtypes = [vp, ctypes.POINTER(u32)]
     L.spp_circuit_msm_sizes.argtypes = [vp, ctypes.POINTER(u32)]
     L.spp_circuit_msm_windows.argtypes = [vp, ctypes.POINTER(u32)]
+    L.spp_circuit_msm_table_rows.argtypes = [vp, ctypes.POINTER(u32)]
     L.spp_circuit_table_bytes.argtypes = [vp]
     L.spp_circuit_table_bytes.restype = ctypes.c_uint64
     L.spp_prove_batch.argtypes = [vp, sz, cp, cp, vp, vp, vp]

@@ -140,6 +140,12 @@ class CircuitHandle:
         check(self.L.spp_circuit_msm_windows(self.h, s))
         return list(s)
 
+    def msm_table_rows(self):
+        """table rows per base and set: 1 = single-row tables walked once per window (window_bits = 0)"""
+        s = (ctypes.c_uint32 * 7)()
+        check(self.L.spp_circuit_msm_table_rows(self.h, s))
+        return list(s)
+
     @property
     def table_bytes(self):
         return int(self.L.spp_circuit_table_bytes(self.h))
