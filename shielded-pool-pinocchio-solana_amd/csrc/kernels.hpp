@@ -158,7 +158,7 @@ struct MsmPlan {
   uint32_t Pp;       // proofs per slice row: P rounded up to a wave (P >= 64), else P
   size_t partial_elems(uint32_t P) const { return (size_t)R * Sg * P; }
 };
-MsmPlan msm_plan(uint32_t N, uint32_t P, uint32_t c, uint32_t Wt);
+MsmPlan msm_plan(uint32_t N, uint32_t P, uint32_t c, uint32_t Wt, uint32_t occ = 2);   // occ: resident waves per SIMD of the kernel (G1 2, G2 1)
 // builds rows [row0, row0 + nrows) (row = base * Wt + m; row0 a multiple of 64) of the table of N bases;
 // tmp / tmp_pre: nrows * 2^(c-1) elements each.  Layout: see kernels_msm.hip.
 template <class F>

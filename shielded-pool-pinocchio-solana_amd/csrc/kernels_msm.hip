@@ -18,6 +18,7 @@
 #include <hip/hip_ext.h>
 #include "kernels.hpp"
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include "f29.hpp"
 
@@ -25,14 +26,18 @@ namespace spp {
 
 uint32_t msm_windows(uint32_t c) { return (254 + c - 1) / c; }
 
-// Lane layout of one launch (see kernels.hpp, MsmPlan).  Big batches: ~256 CUs x 4 SIMDs x 4 waves of lanes, at least 4 bases
-// per slice.  Small batches (a single proof is the drop-in generateProof case): when that cannot give ~64K lanes the table
-// windows of a base are shared by up to 8 lanes (Q chunks of >= 4 windows) and a slice may be a single (base, chunk) item.
-MsmPlan msm_plan(uint32_t N, uint32_t P, uint32_t c, uint32_t Wt) {
-  static const uint32_t waves_per_simd = [] {   // SPP_MSM_WAVES (experiment): lanes launched = 256 CUs x 4 SIMDs x this x 64
+// Lane layout of one launch (see kernels.hpp, MsmPlan).  Big batches: the chip holds 1024 SIMDs x `occ` waves of this kernel at
+// a time (occ = 2 for G1 at ~200 VGPRs, 1 for G2); the waves of a launch take about the same time each, so a launch of w waves
+// runs ceil(w / capacity) rounds and the last, partly filled round costs a whole one.  Sg is therefore searched around
+// SPP_MSM_WAVES (default 4) rounds for the value that fills its last round best (17 passes x 8 slices x 32 waves were 2.125
+// rounds: the 15-bit sets ran 12 % slower per addition than the 16-bit ones until this was done).  At least 4 bases per slice.
+// Small batches (a single proof is the drop-in generateProof case): when that cannot give ~64K lanes the table windows of a base
+// are shared by up to 8 lanes (Q chunks of >= 4 windows) and a slice may be a single (base, chunk) item.
+MsmPlan msm_plan(uint32_t N, uint32_t P, uint32_t c, uint32_t Wt, uint32_t occ) {
+  static const uint32_t rounds = [] {
     const char* e = getenv("SPP_MSM_WAVES");
     const int v = e ? atoi(e) : 4;
-    return (uint32_t)(v >= 1 && v <= 8 ? v : 4);
+    return (uint32_t)(v >= 1 && v <= 16 ? v : 4);
   }();
   MsmPlan pl{};
   pl.W = msm_windows(c);
@@ -49,8 +54,19 @@ MsmPlan msm_plan(uint32_t N, uint32_t P, uint32_t c, uint32_t Wt) {
     S = (65536 + lanes_per_slice - 1) / lanes_per_slice;
     maxS = (uint64_t)N * pl.Q;
   } else {
-    S = ((uint64_t)256 * 4 * waves_per_simd * 64 + lanes_per_slice - 1) / lanes_per_slice;
-    maxS = (N + 3) / 4;
+    maxS = std::max<uint64_t>((N + 3) / 4, 1);
+    const double cap = 1024.0 * (occ ? occ : 1);                       // resident waves
+    const double wps = (double)lanes_per_slice / 64.0;                  // waves per slice (all passes)
+    const uint64_t S0 = std::max<uint64_t>(1, (uint64_t)(rounds * cap / wps + 0.5));
+    uint64_t lo = std::max<uint64_t>(1, S0 - S0 / 4), hi = S0 + S0 / 2;
+    lo = std::min(lo, maxS);
+    hi = std::min(hi, maxS);
+    S = lo;
+    double best = -1;
+    for (uint64_t s = lo; s <= hi; s++) {
+      const double r = s * wps / cap, eff = r / std::ceil(r - 1e-9);
+      if (eff > best + 1e-6) { best = eff; S = s; }
+    }
   }
   if (maxS == 0) maxS = 1;
   if (S > maxS) S = maxS;

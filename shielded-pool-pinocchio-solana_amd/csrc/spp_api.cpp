@@ -1171,10 +1171,11 @@ static int ws_alloc(Workspace& w, T** p, size_t count) {
 template <class F>
 static int ws_set(Workspace& w, const MsmSet<F>* s, MsmBuf<F>* b, size_t P) {
   // R * Sg(P') * P' <= lane target + R * P' for every P' <= P (msm_plan); small batches: up to 64K (item, pass) lanes
-  const uint32_t R = msm_plan(s->N, (uint32_t)P, s->c, s->Wt).R;
+  const uint32_t occ = sizeof(F) > sizeof(Fq) ? 1 : 2;
+  const uint32_t R = msm_plan(s->N, (uint32_t)P, s->c, s->Wt, occ).R;
   b->partial_cap = (size_t)256 * 4 * 8 * 64 + 65536 + (size_t)(R + 1) * (P + 64);
   for (size_t q = P; q >= 1; q /= 2)   // and the exact need at the sizes most likely to be used
-    b->partial_cap = std::max(b->partial_cap, msm_plan(s->N, (uint32_t)q, s->c, s->Wt).partial_elems((uint32_t)q));
+    b->partial_cap = std::max(b->partial_cap, msm_plan(s->N, (uint32_t)q, s->c, s->Wt, occ).partial_elems((uint32_t)q));
   int e;
   if ((e = ws_alloc(w, &b->partial, b->partial_cap))) return e;
   return ws_alloc(w, &b->out, P);
@@ -1221,7 +1222,7 @@ static void run_msm(spp_circuit* c, Workspace& w, const MsmSet<F>& s, MsmBuf<F>&
                     std::pair<hipEvent_t, hipEvent_t>* ev_override = nullptr, bool fold = true, const Fr* scal_override = nullptr) {
   hipStream_t st = st_override ? st_override : w.st;
   const Fr* scal = scal_override ? scal_override : s.from_h ? w.abc : w.W;
-  MsmPlan pl = msm_plan(s.N, P, s.c, s.Wt);
+  MsmPlan pl = msm_plan(s.N, P, s.c, s.Wt, sizeof(F) > sizeof(Fq) ? 1 : 2);
   while (pl.Sg > 1 && pl.partial_elems(P) > b.partial_cap) pl.Sg--;  // never exceed the allocated partial buffer
   b.plan = pl;
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
