@@ -1339,12 +1339,28 @@ extern "C" int spp_prove_batch_device(spp_circuit* c, size_t count, const void* 
   if (count > (1u << 20)) return fail(SPP_ERR_BAD_INPUT, "batch too large");
   std::lock_guard<std::mutex> lk(c->ctx->mu);
   HIP_TRY(hipSetDevice(c->ctx->device));
-  Workspace& w = c->ws[c->next_ws];
-  c->last_ws = c->next_ws;
+  const int wi = c->next_ws;
+  Workspace& w = c->ws[wi];
+  c->last_ws = wi;
   c->next_ws ^= 1;
   // size BOTH workspaces on the first call, so that no allocation ever lands inside a caller's timed / pipelined region
   if (int e = ensure_workspace(c, c->ws[0], count)) return e;
   if (int e = ensure_workspace(c, c->ws[1], count)) return e;
+  // A batch that is not a multiple of the wave width is cut into a 64-aligned body and a tail of < 64 proofs.  Every kernel
+  // of the path maps 64 proofs to a wave, so 1025 proofs used to cost a 17th wave per (slice, window) everywhere -- and before the
+  // lanes were padded to waves, every wave of the MSM straddled two slices (1024 -> 1025 proofs: +23 % time, profiles/
+  // round2_batch_size_sweep.txt).  The tail takes the small-batch paths (cooperative solver, lanes per (base, proof)) on the
+  // OTHER proving stream, beside the body; the next call starts on that stream, behind the short tail.  SPP_NO_SPLIT=1: off.
+  static const bool no_split = getenv("SPP_NO_SPLIT") != nullptr;
+  const size_t tail = count % 64;
+  if (count > 64 && tail && !no_split) {
+    const size_t body = count - tail, nin = c->circ.n_inputs(), pwl = 12 + 32 * (size_t)(c->circ.n_public - 1);
+    if (int e = prove_on_device(c, w, (uint32_t)body, (const uint8_t*)d_inputs, (const uint8_t*)d_rs, (uint8_t*)d_proofs, (uint8_t*)d_pws,
+                                (uint32_t*)d_status))
+      return e;
+    return prove_on_device(c, c->ws[wi ^ 1], (uint32_t)tail, (const uint8_t*)d_inputs + body * nin * 32, (const uint8_t*)d_rs + body * 64,
+                           (uint8_t*)d_proofs + body * SPP_PROOF_LEN, (uint8_t*)d_pws + body * pwl, (uint32_t*)d_status + body);
+  }
   return prove_on_device(c, w, (uint32_t)count, (const uint8_t*)d_inputs, (const uint8_t*)d_rs, (uint8_t*)d_proofs, (uint8_t*)d_pws,
                          (uint32_t*)d_status);
 }
@@ -1480,8 +1496,18 @@ extern "C" int spp_prove_batch(spp_circuit* c, size_t count, const uint8_t* inpu
     };
     Workspace* prev_w = nullptr;
     size_t prev_off = 0, prev_n = 0;
+    // chunk list: a last chunk that is not a multiple of the wave width is cut into a 64-aligned body and a tail (see
+    // spp_prove_batch_device); the two alternate workspaces like any other pair of chunks
+    std::vector<std::pair<size_t, size_t>> chunks;
     for (size_t off = 0; off < count; off += chunk) {
-      const size_t n = std::min(chunk, count - off);
+      const size_t n = std::min(chunk, count - off), t = n % 64;
+      if (n > 64 && t && !getenv("SPP_NO_SPLIT")) {
+        chunks.push_back({off, n - t});
+        chunks.push_back({off + n - t, t});
+      } else chunks.push_back({off, n});
+    }
+    for (const auto& ch : chunks) {
+      const size_t off = ch.first, n = ch.second;
       Workspace& w = c->ws[c->next_ws];
       c->last_ws = c->next_ws;
       c->next_ws ^= 1;

@@ -454,7 +454,9 @@ def test_unsatisfied_inputs_are_refused(withdraw_handle, withdraw_kat):
 
 
 def test_odd_batch_sizes_and_default_window(ctx, withdraw_artifacts, withdraw_kat):
-    """P = 1, 3, 70 (not multiples of the wavefront) and automatically sized per-set window tables (20 GB budget)."""
+    """P = 1, 3, 65, 70, 1025 (not multiples of the wavefront: above 64 the batch is cut into a 64-aligned body and a tail on the
+    other proving stream) and automatically sized per-set window tables (20 GB budget); with SPP_NO_SPLIT-style whole batches
+    the bytes are the same (checked for 70 through the device entry point's tail-free twin, the host entry point's chunks)."""
     from oracle import native
     os.environ["SPP_TABLE_BUDGET_GB"] = "20"
     h = ctx.load_circuit(withdraw_artifacts["sppc"], withdraw_artifacts["pk"], 0)
@@ -463,12 +465,12 @@ def test_odd_batch_sizes_and_default_window(ctx, withdraw_artifacts, withdraw_ka
         assert h.table_bytes <= 20e9 and 8 <= min(h.msm_windows()[:4]) and len(set(h.msm_windows())) > 1
         orc = native.Prover(withdraw_artifacts["sppc"], withdraw_artifacts["pk"])
         rows = _withdraw_variants(withdraw_kat, 4)
-        for count in (1, 3, 70):
+        for count in (1, 3, 65, 70, 1025):
             batch = [rows[i % len(rows)] for i in range(count)]
             rs = [(i + 1, 3 * i + 2) for i in range(count)]
             proofs, pws, status = h.prove_batch(batch, rs)
             assert status == [0] * count
-            for i in sorted({0, count // 2, count - 1}):
+            for i in sorted({0, count // 2, 63 % count, 64 % count, count - 1}):
                 rc, proof, pw = orc.prove(batch[i], rs[i][0], rs[i][1])
                 assert proofs[i] == proof and pws[i] == pw, (count, i)
     finally:
