@@ -17,7 +17,7 @@ RCCL (timed as pk_bcast_ms, outside the metric), and every rank proves its own r
                 spp.multi.shard_range                                    -> "scaling": "strong"
 Rank 0 prints ONE JSON line.  At N = 1 the line also carries the withdraw circuit (own shape, the reference's R1CS size, the
 depth-20 variant), the RLWE witness kernel on 2^16 instances (configs[3]) and the 2^24-point Pippenger MSM (configs[4]).
-`roofline` prices the dominant kernel (k_msm_fixed<G1>) against the HBM peak from a serialised probe (three steps on one
+`roofline` prices the dominant kernel (k_msm_flat<G1>, the table walk of kernels_msm.hip) against the HBM peak from a serialised probe (three steps on one
 stream after the timed region, durations from the dispatches' own timestamps) -- in the pipelined timed region the same
 dispatches share the chip with the other batch and last longer; both figures are in the line.  `cpu_baseline` times the
 oracle's C/OpenMP prover on a bounded sample of the same rows on this host (reported baseline, not the target).
@@ -31,6 +31,7 @@ import sys
 import tempfile
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before torch / HIP initialise: see spp/lib.py (streams of unrelated batches must not share a queue)
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "shielded-pool-pinocchio-solana_amd"))
@@ -58,6 +59,7 @@ def parse_args(argv=None):
     ap.add_argument("--window", type=int, default=int(os.environ.get("SPP_WINDOW", "0")), help="MSM window bits; 0 = auto (largest tables within the HBM budget)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline circuit only (profiling runs)")
+    ap.add_argument("--no-other-circuits", action="store_true", help="headline circuit with its own legs (rehearsal, end to end), none of the other circuits / configs")
     ap.add_argument("--ccs-leg-only", action="store_true", help="diagnostic: only the leg that proves the reference's own gnark R1CS")
     ap.add_argument("--no-single", action="store_true", help="skip the single-proof latency leg (keeps profiler per-kernel averages clean)")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the host-buffer (PCIe-inclusive) leg: its chunks overlap on two workspaces and would "
@@ -78,11 +80,40 @@ def launch_ranks(args, argv):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
+    # a rank stuck in a rendezvous must not hold the run until the driver's own limit: SPP_BENCH_RANK_TIMEOUT_S (default 1500)
+    # for the whole run; on expiry -- or as soon as one rank has failed and the others have had a minute to notice -- the
+    # remaining children (fresh processes started above, nothing else) are terminated, then killed, and the exit code is 124
+    limit = float(os.environ.get("SPP_BENCH_RANK_TIMEOUT_S", "1500"))
+    t_end = time.time() + limit
+    rc, failed_at = 0, None
+    while any(p.poll() is None for p in procs):
+        now = time.time()
+        for p in procs:
+            if p.returncode not in (None, 0) and failed_at is None:
+                failed_at, rc = now, p.returncode
+        if now > t_end or (failed_at is not None and now - failed_at > 60.0):
+            print("bench.py: rank processes still running after %s; terminating them" % ("%.0f s" % limit if now > t_end else "a rank failed"), file=sys.stderr)
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t_kill = time.time() + 10.0
+            while time.time() < t_kill and any(p.poll() is None for p in procs):
+                time.sleep(0.1)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            for p in procs:
+                p.wait()
+            return rc or 124
+        time.sleep(0.2)
     for p in procs:
-        p.wait()
         rc = rc or p.returncode
     return rc
+
+
+def libspp_sha256():
+    import hashlib
+    return hashlib.sha256(open(os.path.join(ROOT, "shielded-pool-pinocchio-solana_amd", "libspp.so"), "rb").read()).hexdigest()
 
 
 def dry_run(args, rank, world, dist, coll_dev):
@@ -390,6 +421,71 @@ def main():
                 probe["stage"][i] += tm[i]
         h.set_serial(False)
 
+        # ---- BASELINE.json configs[2] rehearsed on ONE GPU: 1 024 audit proofs over 8 GPUs are 128 per rank and step.  The same
+        # handle proves the first 128 rows of this rank's batch, pipelined exactly like the headline (libspp keeps up to four
+        # such batches in flight); its rate beside the 2 048-proof rate is what one rank of a strong-scaling run delivers.
+        def pipelined_rate(Bs, n_steps, n_warm):
+            outs = [(torch.zeros(Bs * 388, dtype=torch.uint8, device=dev), torch.zeros(Bs * h.pw_len, dtype=torch.uint8, device=dev),
+                     torch.zeros(Bs, dtype=torch.int32, device=dev)) for _ in range(4)]
+            def go(i):
+                pr, pw, st_ = outs[i & 3]
+                h.prove_batch_device(Bs, inp.data_ptr(), rs.data_ptr(), pr.data_ptr(), pw.data_ptr(), st_.data_ptr())
+            for i in range(n_warm):
+                go(i)
+            h.sync(); torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for i in range(n_steps):
+                go(n_warm + i)
+            h.sync(); torch.cuda.synchronize()
+            el = time.perf_counter() - ts
+            assert sum(int(o[2].abs().sum().item()) for o in outs) == 0
+            assert bytes(outs[0][0].cpu().numpy()) == bytes(outs[1][0].cpu().numpy()), "the batches in flight disagree"
+            return Bs * n_steps / el, el / n_steps * 1e3
+
+        rehearsal = None
+        if circuit == "audit" and not strong_total and world == 1 and not args.no_extras and B >= 1024:
+            rate128, ms128 = pipelined_rate(128, 48, 8)
+            rehearsal = {"what": "one of 8 ranks of `--mode strong --total 1024` (BASELINE.json configs[2]): 128 audit proofs per step, pipelined",
+                         "batch": 128, "value": round(rate128, 1), "unit": "proofs/s", "ms_per_step": round(ms128, 3), "steps": 48, "warmup": 8,
+                         "fraction_of_the_%d_proof_rate" % B: round(rate128 / (total_proofs * steps / elapsed), 4),
+                         "note": "predicted per-GPU efficiency of the literal strong-scaling config; weak scaling (2 048 per GPU) has no such loss"}
+
+        # ---- end to end: (sk, r, e1, e2) -> proof.  Everything scripts/generate_audit.py:468-641 computes before `nargo execute`
+        # (keygen, wa_commitment, RLWE encryption + quotients, packing, ct_commitment) runs on the device INSIDE the clock, each
+        # step from the raw secrets of its batch; the rows it produces are checked against the ones the headline used.
+        e2e = None
+        if circuit == "audit" and not strong_total and world == 1 and not args.no_extras:
+            import numpy as np
+            from spp.lib import check as spp_check
+            sks, r8, e18, e28 = workload.audit_noise(lo, B)
+            up = lambda raw: torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+            d_a, d_b = up(np.asarray(rlwe_pk["a"], dtype=np.uint32).tobytes()), up(np.asarray(rlwe_pk["b"], dtype=np.uint32).tobytes())
+            d_sk = up(b"".join(int(v).to_bytes(32, "big") for v in sks))
+            d_r, d_e1, d_e2 = up(r8.tobytes()), up(e18.tobytes()), up(e28.tobytes())
+            d_rows = [torch.zeros(B * h.n_inputs * 32, dtype=torch.uint8, device=dev) for _ in range(2)]
+
+            def e2e_step(i):
+                k = i & 1
+                spp_check(ctx.L.spp_audit_inputs_batch_device(ctx.h, d_a.data_ptr(), d_b.data_ptr(), B, d_sk.data_ptr(), d_r.data_ptr(),
+                                                              d_e1.data_ptr(), d_e2.data_ptr(), d_rows[k].data_ptr()))
+                h.prove_batch_device(B, d_rows[k].data_ptr(), rs.data_ptr(), proofs[k].data_ptr(), pws[k].data_ptr(), status[k].data_ptr())
+                if i >= 1:
+                    h.last_timings(1)     # wait for the batch before: its row buffer is the next one to be overwritten
+            for i in range(2):
+                e2e_step(i)
+            h.sync(); torch.cuda.synchronize()
+            assert torch.equal(d_rows[0], inp) and torch.equal(d_rows[1], inp), "device-built rows differ from the headline's rows"
+            ts = time.perf_counter()
+            n_e2e = max(6, steps)
+            for i in range(n_e2e):
+                e2e_step(i)
+            h.sync(); torch.cuda.synchronize()
+            el = time.perf_counter() - ts
+            assert int(status[0].abs().sum().item()) + int(status[1].abs().sum().item()) == 0
+            e2e = {"what": "clock starts at (secret_key, r, e1, e2) resident in HBM: spp_audit_inputs_batch_device + spp_prove_batch_device per step",
+                   "value": round(B * n_e2e / el, 1), "unit": "proofs/s", "ms_per_step": round(el / n_e2e * 1e3, 3), "steps": n_e2e,
+                   "rows_equal_the_headline_rows": True}
+
         # the same rows through the host-buffer entry point (spp_prove_batch: H2D of the inputs, D2H of proofs / public
         # witnesses, synchronous): the PCIe-inclusive rate, reported beside `value`, never as `value`
         import ctypes
@@ -453,7 +549,7 @@ def main():
         ms_per_step = elapsed / steps * 1e3
         sizes = dict(zip(INFO_ORDER, h.msm_sizes()))
         windows = dict(zip(INFO_ORDER, h.msm_windows()))
-        # algorithmic bytes of one k_msm_fixed launch over a batch (64 B per base once + one 32 B scalar per (base, proof))
+        # algorithmic bytes of one k_msm_flat launch over a batch (64 B per base once + one 32 B scalar per (base, proof))
         alg = {s: (128 if s.startswith("B2") else 64) * sizes[s] + 32 * sizes[s] * B for s in SETS}
         g1 = SETS[:6]
         ser = {s: probe["kern"][i] / probe["n"] for i, s in enumerate(SETS)}
@@ -464,7 +560,10 @@ def main():
         traffic, traffic_src, valu_util = None, None, None
         try:   # PMC passes of the same workload, committed under profiles/ (rocprofv3 --pmc cannot run inside this process)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_latest.json")))
-            if pmc.get("circuit") == circuit and pmc.get("batch") == B and pmc.get("n_distinct_witnesses") == B:
+            # ... and only of THIS library: the file records the sha256 of the libspp.so the counters were taken on, so a kernel
+            # change cannot inherit an older kernel's traffic
+            if pmc.get("circuit") == circuit and pmc.get("batch") == B and pmc.get("n_distinct_witnesses") == B \
+                    and pmc.get("libspp_sha256") == libspp_sha256():
                 traffic = pmc["k_msm_fixed_g1_hbm_bytes_per_launch"]
                 traffic_src = pmc.get("source")
                 valu_util = pmc.get("k_msm_fixed_g1_valu_issue_util_serialised")
@@ -484,7 +583,7 @@ def main():
                 ["solve+commit", "matrix_eval", "ntt_qap", "msm_g1", "msm_g2_side_stream_join", "assemble", "total"], acc["stage"])},
             "stage_ms_per_step_serialised": {k: round(v / probe["n"], 3) for k, v in zip(
                 ["solve+commit", "matrix_eval", "ntt_qap", "msm_g1", "msm_g2", "assemble", "total"], probe["stage"])},
-            "roofline": {"bound": "hbm", "kernel": "k_msm_fixed<Fq>", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_msm_flat<Fq>", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "alg_bytes_per_launch": int(alg_g1 / 6), "avg_launch_ms": round(ser_g1_ms / 6, 4), "launches_per_step": 6,
                          "launch_ms_serialised": {s: round(ser[s], 3) for s in SETS},
@@ -493,10 +592,16 @@ def main():
                          "timing": "dispatch timestamps (hipExtLaunchKernelGGL events); `achieved` uses the serialised probe (3 steps on one stream after "
                                    "the timed region): 6 launches x avg_launch_ms <= ms_per_step; in the pipelined region the same dispatches share the chip",
                          "valu_issue_util_pmc": valu_util,
-                         "note": "integer-VALU bound (about 2.3K instructions, 1.5K of them v_mad_u64_u32, per mixed addition); HBM fraction reported as mandated"},
+                         "msm_table_rows": dict(zip(INFO_ORDER, h.msm_table_rows())),
+                         "note": "integer-VALU bound (about 2.3K instructions, 1.5K of them v_mad_u64_u32, per mixed addition; 16-17 additions per "
+                                 "full-size scalar with single-row 15/16-bit tables); HBM fraction of the algorithmic bytes reported as mandated"},
         }
         if single is not None:
             out["single_proof"] = single
+        if rehearsal is not None:
+            out["strong_scaling_rank_rehearsal"] = rehearsal
+        if e2e is not None:
+            out["audit_end_to_end_from_secrets"] = e2e
         if want_cpu:
             orc = native.Prover(sppc, pkp)
             cores = native.max_threads()
@@ -602,7 +707,7 @@ def main():
     B0 = args.batch or DEFAULT_BATCH[args.circuit]
     main_res = run_circuit(args.circuit, B0, args.steps, args.warmup, not args.no_cpu_baseline and world == 1, args.total if strong else 0)
     extras = {}
-    if world == 1 and not args.no_extras and not strong:
+    if world == 1 and not args.no_extras and not args.no_other_circuits and not strong:
         # the other circuits / configs of BASELINE.json, each at >= 10 timed steps, in the same line so that the driver times them
         want = not args.no_cpu_baseline
         other = "withdraw" if args.circuit == "audit" else "audit"
@@ -622,7 +727,8 @@ def main():
         line = {"metric": "Groth16 proofs/sec", "value": main_res["value"], "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": args.mode,
                 "vs_baseline": None, "dtype": "u32x8 (254-bit Montgomery integers)", "data": "synthetic"}
-        for k in ("config", "stage_ms_per_step_pipelined", "stage_ms_per_step_serialised", "roofline", "cpu_baseline", "single_proof"):
+        for k in ("config", "stage_ms_per_step_pipelined", "stage_ms_per_step_serialised", "roofline", "cpu_baseline", "single_proof",
+                  "strong_scaling_rank_rehearsal", "audit_end_to_end_from_secrets"):
             if k in main_res:
                 line[k] = main_res[k]
         line.update(extras)

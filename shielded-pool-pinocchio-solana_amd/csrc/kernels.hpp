@@ -177,12 +177,13 @@ template <class F>
 void launch_msm_reduce(hipStream_t st, XYZZ<F>* partial, XYZZ<F>* out, uint32_t P, const MsmPlan& pl, uint32_t c, bool empty);
 // several sets folded by the same launches (one launch per level for all of them, one Horner launch)
 static constexpr uint32_t MSM_FOLD_SETS = 8;
+static constexpr uint32_t MSM_FOLD_RADIX = 8;   // slices summed per lane and fold level
 template <class F>
 struct MsmFoldSets {
   XYZZ<F>* partial[MSM_FOLD_SETS];
   XYZZ<F>* out[MSM_FOLD_SETS];
   uint32_t Sg[MSM_FOLD_SETS], R[MSM_FOLD_SETS], c[MSM_FOLD_SETS];   // per set: slices per pass (0 = empty set), passes, window bits
-  uint32_t cur[MSM_FOLD_SETS], half[MSM_FOLD_SETS];                 // filled per level by launch_msm_reduce_multi
+  uint32_t cur[MSM_FOLD_SETS], half[MSM_FOLD_SETS];                 // per level: slices before / after it (launch_msm_reduce_multi)
 };
 template <class F>
 void launch_msm_reduce_multi(hipStream_t st, MsmFoldSets<F> fs, uint32_t nsets, uint32_t P);

@@ -57,7 +57,10 @@ MsmPlan msm_plan(uint32_t N, uint32_t P, uint32_t c, uint32_t Wt, uint32_t occ) 
     maxS = std::max<uint64_t>((N + 3) / 4, 1);
     const double cap = 1024.0 * (occ ? occ : 1);                       // resident waves
     const double wps = (double)lanes_per_slice / 64.0;                  // waves per slice (all passes)
-    const uint64_t S0 = std::max<uint64_t>(1, (uint64_t)(rounds * cap / wps + 0.5));
+    // small batches wait on every dependent launch for SIMDs to come free: shorter waves (three times as many rounds) let the
+    // short kernels of the other batches in flight start sooner (128-proof audit batches, four in flight: +2 %)
+    const uint32_t rnd = P <= 256 ? 3 * rounds : rounds;
+    const uint64_t S0 = std::max<uint64_t>(1, (uint64_t)(rnd * cap / wps + 0.5));
     uint64_t lo = std::max<uint64_t>(1, S0 - S0 / 4), hi = S0 + S0 / 2;
     lo = std::min(lo, maxS);
     hi = std::min(hi, maxS);
@@ -387,25 +390,26 @@ void launch_msm_accumulate(hipStream_t st, const Affine<F>* table, const int16_t
                           pl.W, pl.Sg, pl.Q, pl.Wq);
 }
 
-// Fold the Sg slice sums of every (set, pass, proof): pairwise, one launch per level, every lane busy -- lane (s, p) with
-// s < S_cur - half adds partial[s + half][p] into partial[s][p] (half = ceil(S_cur / 2)).  blockIdx.y = set, blockIdx.z =
-// pass; up to MSM_FOLD_SETS sets share the launches (the five G1 sums of a proof are independent: one launch per level for
-// all of them instead of one per level and set takes most of the ~9 us launches off a single proof).  A set with one pass
-// leaves the fold in out[p]; with R > 1 passes the pass sums stay in partial[rho * Sg * P + p] for k_msm_horner.
+// Fold the Sg slice sums of every (set, pass, proof): radix 8, one launch per level, every lane busy -- lane (s, p) with
+// s < next = ceil(S_cur / 8) adds partial[s + next * m][p], m = 1 .. 7, into partial[s][p].  (Pairwise levels were 8 dependent
+// launches for the 192 slices of a 128-proof batch; behind a chip full of MSM waves every launch waits for free SIMDs, the
+// G2 fold with its 256 registers longest: 0.7 ms per level in the trace of pipelined 128-proof batches.)  blockIdx.y = set,
+// blockIdx.z = pass; up to MSM_FOLD_SETS sets share the launches (the five G1 sums of a proof are independent).  A set with
+// one pass leaves the fold in out[p]; with R > 1 passes the pass sums stay in partial[rho * Sg * P + p] for k_msm_horner.
 template <class F>
 __global__ void __launch_bounds__(64) k_msm_fold_multi(MsmFoldSets<F> fs, uint32_t P) {
   const uint32_t set = blockIdx.y, rho = blockIdx.z;
-  const uint32_t half = fs.half[set], S_cur = fs.cur[set];
-  if (half == 0 || rho >= fs.R[set]) return;   // this set is already folded / has fewer passes
+  const uint32_t next = fs.half[set], S_cur = fs.cur[set];
+  if (next == 0 || rho >= fs.R[set]) return;   // this set is already folded / has fewer passes
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t pairs = S_cur - half;
-  if (g >= half * P) return;
+  if (g >= next * P) return;
   XYZZ<F>* __restrict__ partial = fs.partial[set] + (size_t)rho * fs.Sg[set] * P;
   const uint32_t s = g / P, p = g % P;
   XYZZ<F> a = partial[(size_t)s * P + p];
-  if (s < pairs) a.add(partial[(size_t)(s + half) * P + p]);
-  if (half == 1 && fs.R[set] == 1) fs.out[set][p] = a;   // last level of a one-pass set: the result leaves the scratch array
-  else if (s < pairs) partial[(size_t)s * P + p] = a;
+#pragma unroll 1
+  for (uint32_t t = s + next; t < S_cur; t += next) a.add(partial[(size_t)t * P + p]);
+  if (next == 1 && fs.R[set] == 1) fs.out[set][p] = a;   // last level of a one-pass set: the result leaves the scratch array
+  else partial[(size_t)s * P + p] = a;
 }
 // out[p] = sum_rho 2^(c*rho) * pass_sum[rho][p]  (Horner from the top pass down; one lane per (set, proof))
 template <class F>
@@ -455,7 +459,7 @@ void launch_msm_reduce_multi(hipStream_t st, MsmFoldSets<F> fs, uint32_t nsets, 
   for (;;) {
     uint64_t lanes = 0;
     for (uint32_t i = 0; i < nsets; i++) {
-      fs.half[i] = done[i] ? 0 : (cur[i] + 1) / 2;
+      fs.half[i] = done[i] ? 0 : (cur[i] + MSM_FOLD_RADIX - 1) / MSM_FOLD_RADIX;
       fs.cur[i] = cur[i];
       lanes = std::max<uint64_t>(lanes, (uint64_t)fs.half[i] * P);
     }

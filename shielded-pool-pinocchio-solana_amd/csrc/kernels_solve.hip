@@ -11,6 +11,7 @@
 #include "kernels.hpp"
 #include "circuit.hpp"   // opcodes only
 #include "poseidon29.hpp"
+#include "lanes.hpp"
 #include "sha256.hpp"
 
 namespace spp {
@@ -396,30 +397,6 @@ void launch_solve(hipStream_t st, DevCircuit dc, Fr* W, Fr* scratch, uint32_t pc
 //   COOP_POSEIDON2 different lanes -- three dependent multiplications per partial round instead of 13 (t = 3) / 8
 //   COOP_GRUMPKIN  the fixed-base ladder as a 64-lane prefix sum, one window per lane
 // The values written are the same field elements as the one-lane solver's (the words may be another representative < 2p).
-__device__ __forceinline__ Fr lane_get(const Fr& v, uint32_t src) {
-  Fr r;
-  SPP_UNROLL for (int i = 0; i < 8; i++) r.l[i] = (uint32_t)__shfl((int)v.l[i], (int)src);
-  return r;
-}
-// the value of one FIXED lane in every lane: v_readlane_b32 (scalar path) instead of the LDS crossbar of ds_bpermute
-template <int SRC>
-__device__ __forceinline__ Fr lane_bcast(const Fr& v) {
-  Fr r;
-  SPP_UNROLL for (int i = 0; i < 8; i++) r.l[i] = (uint32_t)__builtin_amdgcn_readlane((int)v.l[i], SRC);
-  return r;
-}
-// lane ^ 1 / lane ^ 2 inside each quad: one DPP move per word (quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E)
-template <int CTRL>
-__device__ __forceinline__ Fr lane_quad(const Fr& v) {
-  Fr r;
-  SPP_UNROLL for (int i = 0; i < 8; i++) r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[i], CTRL, 0xF, 0xF, true);
-  return r;
-}
-__device__ __forceinline__ Fr lane_sel(bool c, const Fr& a, const Fr& b) {
-  Fr r;
-  SPP_UNROLL for (int i = 0; i < 8; i++) r.l[i] = c ? a.l[i] : b.l[i];
-  return r;
-}
 __device__ __forceinline__ void emit4(Fr* __restrict__ W, uint32_t out, uint32_t P, uint32_t p, const Fr& x2, const Fr& x3, const Fr& x4,
                                       const Fr& x5) {
   W[(size_t)out * P + p] = x2;
@@ -428,58 +405,14 @@ __device__ __forceinline__ void emit4(Fr* __restrict__ W, uint32_t out, uint32_t
   W[(size_t)(out + 3) * P + p] = x5;
 }
 
-// Poseidon2 (t = 4): lanes 0..3 hold the state, lanes 4..7 compute x^4 next to x^3 (full rounds); in a partial round lane 4
-// carries mu_0 * x alongside the S-box of lane 0, so that mu_0 * x^5 = (mu_0 * x) * x^4 is ready together with x^5.
+// Poseidon2 (t = 4) in lane-parallel form: lanes.hpp, coop_p2_permute; the S-box powers go to the witness as they appear
 __device__ __noinline__ void coop_poseidon2(const DevCircuit& dc, Fr* __restrict__ W, uint32_t h0, uint32_t out, uint32_t P, uint32_t p,
                                             uint32_t lane) {
-  const uint32_t l4 = lane & 3;
   Fr s = Fr::zero();
   if (lane < 4) s = dev_row_dot(dc.H, dc.coeffs, h0 + lane, 0, W, P, p);
-  const Fr mu = dc.p2_mu[l4];
-  auto external = [&](const Fr& mine) {   // rows (5,7,1,3),(4,6,1,1),(1,3,5,7),(1,1,4,6) of the state held by lanes 0..3
-    const Fr x = lane_bcast<0>(mine), y = lane_bcast<1>(mine), z = lane_bcast<2>(mine), w = lane_bcast<3>(mine);
-    const Fr t0 = x + y, t1 = z + w, t2 = y.dbl() + t1, t3 = w.dbl() + t0;
-    const Fr t4 = t1.dbl().dbl() + t3, t5 = t0.dbl().dbl() + t2;
-    const Fr t6 = t3 + t5, t7 = t2 + t4;
-    return lane_sel(l4 < 2, lane_sel(l4 == 0, t6, t5), lane_sel(l4 == 2, t7, t4));
-  };
-  s = external(s);
-  uint32_t k = 0;
-  auto full_round = [&]() {
-    const Fr x = s + dc.p2_rc[k + l4];
-    const Fr x2 = x * x;
-    const Fr t = lane_get(x2, l4);                       // lanes 4..7: x^2 of lane - 4
-    const Fr R = t * lane_sel(lane < 4, x, t);           // lanes 0..3: x^3, lanes 4..7: x^4
-    const Fr x4 = lane_get(R, l4 + 4);
-    const Fr x5 = x4 * x;
-    if (lane < 4) emit4(W, out + 4 * lane, P, p, x2, R, x4, x5);
-    out += 16;
-    k += 4;
-    s = external(x5);
-  };
-#pragma unroll 1
-  for (int r = 0; r < 4; r++) full_round();
-#pragma unroll 1
-  for (int r = 0; r < 56; r++) {
-    const Fr x = s + dc.p2_rc[k];                        // lane 0
-    const Fr x0 = lane_bcast<0>(x);
-    const Fr R1 = lane_sel(lane == 0, x0, lane_sel(lane < 4, s, x0)) * lane_sel(lane == 0, x0, mu);
-    // R1: lane 0 x^2 | lanes 1..3 mu_i * s_i | lane 4 mu_0 * x
-    const Fr x2 = lane_bcast<0>(R1);
-    const Fr R2 = x2 * lane_sel(lane == 0, x0, x2);      // lane 0 x^3 | lane 4 x^4
-    const Fr x4 = lane_bcast<4>(R2);
-    const Fr R3 = x4 * lane_sel(lane == 0, x0, R1);      // lane 0 x^5 | lane 4 mu_0 * x^5
-    if (lane == 0) emit4(W, out, P, p, R1, R2, x4, R3);
-    out += 4;
-    k += 1;
-    const Fr val = lane_sel(lane == 0, R3, s);
-    Fr tot = val + lane_quad<0xB1>(val);
-    tot = tot + lane_quad<0x4E>(tot);
-    const Fr m0 = lane_bcast<4>(R3);
-    s = lane_sel(lane == 0, m0, R1) + tot;
-  }
-#pragma unroll 1
-  for (int r = 0; r < 4; r++) full_round();
+  coop_p2_permute(dc.p2_rc, dc.p2_mu, s, lane, [&](uint32_t o, const Fr& x2, const Fr& x3, const Fr& x4, const Fr& x5) {
+    emit4(W, out + o, P, p, x2, x3, x4, x5);
+  });
 }
 
 // Poseidon (t = 3, 5): lanes 0..T-1 hold the state; lanes 8+i the x^4 halves (full rounds) or M[i][0] * x (partial rounds);

@@ -10,6 +10,7 @@
 //   k_poseidon2_sponge    ct_helper/src/main.nr:15-34 (= scripts/generate_audit.py:355-374)
 #include "kernels.hpp"
 #include "poseidon29.hpp"
+#include "lanes.hpp"
 #include "rlwe_ntt.hpp"
 
 namespace spp {
@@ -434,8 +435,32 @@ __global__ void __launch_bounds__(64) k_poseidon2_sponge(HashConsts hc, const ui
   poseidon2_permute(s, hc.p2_rc, hc.p2_mu);
   store_be(out_be + (size_t)g * 32, s[0]);
 }
+// Small counts (one audit proof through generateAuditProof, the tail of a batch): one WAVE per instance, the permutation in the
+// lane-parallel form the cooperative solver uses (lanes.hpp: three dependent products per round instead of eight) -- 53 chained
+// permutations are what a single instance waits for.  A wave spends 64 lanes' worth of issue slots on one instance, so large
+// counts keep one lane per instance: 2 048 instances are 32 waves there (latency-bound, hidden behind the proving streams) and
+// would be 2 048 waves x 53 permutations of chip time here.
+__global__ void __launch_bounds__(64) k_poseidon2_sponge_coop(HashConsts hc, const uint8_t* __restrict__ in_be, uint32_t n,
+                                                              uint8_t* __restrict__ out_be, uint32_t count) {
+  const uint32_t g = blockIdx.x, lane = threadIdx.x;
+  if (g >= count) return;
+  const uint8_t* in = in_be + (size_t)g * n * 32;
+  auto no_emit = [](uint32_t, const Fr&, const Fr&, const Fr&, const Fr&) {};
+  Fr s = Fr::zero();
+  const uint32_t full = n / 3, rem = n - 3 * full;
+#pragma unroll 1
+  for (uint32_t i = 0; i < full; i++) {
+    if (lane < 3) s = s + load_be(in + (size_t)(3 * i + lane) * 32);
+    s = coop_p2_permute(hc.p2_rc, hc.p2_mu, s, lane, no_emit);
+  }
+  if (lane < rem) s = s + load_be(in + (size_t)(3 * full + lane) * 32);
+  s = coop_p2_permute(hc.p2_rc, hc.p2_mu, s, lane, no_emit);
+  if (lane == 0) store_be(out_be + (size_t)g * 32, s);
+}
 void launch_poseidon2_sponge(hipStream_t st, HashConsts hc, const uint8_t* in_be, uint32_t n, uint8_t* out_be, uint32_t count) {
-  if (count) hipLaunchKernelGGL(k_poseidon2_sponge, dim3((count + 63) / 64), dim3(64), 0, st, hc, in_be, n, out_be, count);
+  if (count == 0) return;
+  if (count <= 256) hipLaunchKernelGGL(k_poseidon2_sponge_coop, dim3(count), dim3(64), 0, st, hc, in_be, n, out_be, count);
+  else hipLaunchKernelGGL(k_poseidon2_sponge, dim3((count + 63) / 64), dim3(64), 0, st, hc, in_be, n, out_be, count);
 }
 
 

@@ -99,8 +99,8 @@ struct spp_circuit {
   Fr zinv;
   // device copies owned here
   std::vector<void*> owned;
-  Workspace ws[2];
-  int next_ws = 0, last_ws = 0;
+  Workspace ws[SPP_NWS];
+  int next_ws = 0, last_ws = 0, prev_ws = 0;   // prev_ws: the workspace of the batch before the last one (spp_timings which = 1)
   std::vector<PendingTable<Fq>> pending1;    // tables allocated but not yet built (spp_load_circuit)
   std::vector<PendingTable<Fq2>> pending2;
 };
@@ -629,7 +629,8 @@ extern "C" int spp_init(int device, spp_ctx** out) {
   ctx->device = device;
   HIP_TRY(hipStreamCreate(&ctx->stream));
   HIP_TRY(hipStreamCreate(&ctx->pstream[0]));
-  if (int e = pick_concurrent_stream(ctx->pstream[0], &ctx->pstream[1])) return e;
+  for (int k = 1; k < SPP_NWS; k++)
+    if (int e = pick_concurrent_stream(ctx->pstream[0], &ctx->pstream[k])) return e;
   *out = ctx;
   return SPP_OK;
 }
@@ -668,9 +669,9 @@ extern "C" void spp_free_ctx(spp_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   hipStreamDestroy(ctx->stream);
-  hipStreamDestroy(ctx->pstream[0]);
-  hipStreamDestroy(ctx->pstream[1]);
+  for (int k = 0; k < SPP_NWS; k++) hipStreamDestroy(ctx->pstream[k]);
   for (void* p : ctx->owned) hipFree(p);
+  if (ctx->audit_scratch) hipFree(ctx->audit_scratch);
   delete ctx;
 }
 
@@ -1075,7 +1076,7 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
   if ((e = make_set(c, &c->CS, pk.CS_w, pk.CS, false, cw[5], false))) return e;
   if ((e = build_pending(c))) return e;
 
-  for (int k = 0; k < 2; k++) {
+  for (int k = 0; k < SPP_NWS; k++) {
     Workspace& w = c->ws[k];
     // SPP_SERIAL=1 (profiling aid): one stream for everything, so per-stage / per-kernel times are not stretched by
     // the other batch or by the G2 side stream
@@ -1282,7 +1283,9 @@ static int prove_on_device(spp_circuit* c, Workspace& w, uint32_t P, const uint8
   hipEventRecord(w.ev[1], st);
   // the G2 MSM depends on the witness only: start it now on the side stream
   hipEventRecord(w.ev_w, st);
+  static const bool no_side = getenv("SPP_NO_SIDE") != nullptr;   // experiment: the G2 sum on the batch's own stream
   hipStream_t side = (w.st2 != w.st && w.own_st2p && P > COOP_MAX_BATCH) ? w.own_st2p : w.st2;
+  if (no_side && P <= COOP_MAX_BATCH) side = st;
   hipStreamWaitEvent(side, w.ev_w, 0);
   run_msm(c, w, c->B2, w.B2, P, false, side, &w.g2_ev);
   hipEventRecord(w.ev_b2, side);
@@ -1332,6 +1335,15 @@ static int prove_on_device(spp_circuit* c, Workspace& w, uint32_t P, const uint8
   return SPP_OK;
 }
 
+static int ws_depth(size_t count) {
+  static const int forced = [] {   // SPP_DEPTH (experiment): batches in flight, 1 .. SPP_NWS
+    const char* e = getenv("SPP_DEPTH");
+    const int v = e ? atoi(e) : 0;
+    return v >= 1 && v <= SPP_NWS ? v : 0;
+  }();
+  if (forced) return forced;
+  return count <= 256 ? 4 : count <= 768 ? 3 : 2;
+}
 extern "C" int spp_prove_batch_device(spp_circuit* c, size_t count, const void* d_inputs, const void* d_rs, void* d_proofs, void* d_pws,
                                       void* d_status) {
   if (!c || !d_inputs || !d_rs || !d_proofs || !d_pws || !d_status) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
@@ -1339,13 +1351,19 @@ extern "C" int spp_prove_batch_device(spp_circuit* c, size_t count, const void* 
   if (count > (1u << 20)) return fail(SPP_ERR_BAD_INPUT, "batch too large");
   std::lock_guard<std::mutex> lk(c->ctx->mu);
   HIP_TRY(hipSetDevice(c->ctx->device));
-  const int wi = c->next_ws;
+  // Batches in flight: two for big batches (more adds nothing once the latency-bound phases are covered: DESIGN 8.3); small
+  // batches -- 128 proofs are one of 8 ranks' share of BASELINE.json configs[2] -- spend a larger part of their time in
+  // latency-bound kernels (11 ms of sponge chain in the solver, the Horner combines), so up to four take turns.
+  const int depth = ws_depth(count);
+  if (c->next_ws >= depth) c->next_ws = 0;
+  const int wi = c->next_ws, wo = (wi + 1) % depth;
   Workspace& w = c->ws[wi];
+  c->prev_ws = c->last_ws;
   c->last_ws = wi;
-  c->next_ws ^= 1;
-  // size BOTH workspaces on the first call, so that no allocation ever lands inside a caller's timed / pipelined region
-  if (int e = ensure_workspace(c, c->ws[0], count)) return e;
-  if (int e = ensure_workspace(c, c->ws[1], count)) return e;
+  c->next_ws = wo;
+  // size the workspaces on the first call, so that no allocation ever lands inside a caller's timed / pipelined region
+  for (int k = 0; k < depth; k++)
+    if (int e = ensure_workspace(c, c->ws[k], count)) return e;
   // A batch that is not a multiple of the wave width is cut into a 64-aligned body and a tail of < 64 proofs.  Every kernel
   // of the path maps 64 proofs to a wave, so 1025 proofs used to cost a 17th wave per (slice, window) everywhere -- and before the
   // lanes were padded to waves, every wave of the MSM straddled two slices (1024 -> 1025 proofs: +23 % time, profiles/
@@ -1358,7 +1376,7 @@ extern "C" int spp_prove_batch_device(spp_circuit* c, size_t count, const void* 
     if (int e = prove_on_device(c, w, (uint32_t)body, (const uint8_t*)d_inputs, (const uint8_t*)d_rs, (uint8_t*)d_proofs, (uint8_t*)d_pws,
                                 (uint32_t*)d_status))
       return e;
-    return prove_on_device(c, c->ws[wi ^ 1], (uint32_t)tail, (const uint8_t*)d_inputs + body * nin * 32, (const uint8_t*)d_rs + body * 64,
+    return prove_on_device(c, c->ws[wo], (uint32_t)tail, (const uint8_t*)d_inputs + body * nin * 32, (const uint8_t*)d_rs + body * 64,
                            (uint8_t*)d_proofs + body * SPP_PROOF_LEN, (uint8_t*)d_pws + body * pwl, (uint32_t*)d_status + body);
   }
   return prove_on_device(c, w, (uint32_t)count, (const uint8_t*)d_inputs, (const uint8_t*)d_rs, (uint8_t*)d_proofs, (uint8_t*)d_pws,
@@ -1400,15 +1418,15 @@ extern "C" int spp_commitment_challenge(spp_circuit* c, size_t count, const uint
 extern "C" int spp_sync(spp_circuit* c) {
   if (!c) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
   HIP_TRY(hipSetDevice(c->ctx->device));
-  HIP_TRY(hipStreamSynchronize(c->ws[0].st));
-  HIP_TRY(hipStreamSynchronize(c->ws[1].st));
+  for (auto& w : c->ws)
+    if (w.st) HIP_TRY(hipStreamSynchronize(w.st));
   return SPP_OK;
 }
 extern "C" int spp_last_timings(spp_circuit* c, float ms[9]) { return spp_timings(c, 0, ms); }
 extern "C" int spp_timings(spp_circuit* c, int which, float ms[9]) {
   if (!c || !ms) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
   HIP_TRY(hipSetDevice(c->ctx->device));
-  Workspace& w = c->ws[which ? c->last_ws ^ 1 : c->last_ws];
+  Workspace& w = c->ws[which ? c->prev_ws : c->last_ws];
   if (w.cap == 0) return fail(SPP_ERR_BAD_INPUT, "no such batch");
   HIP_TRY(hipStreamSynchronize(w.st));
   for (int i = 0; i < 6; i++) {
@@ -1434,7 +1452,7 @@ extern "C" int spp_timings(spp_circuit* c, int which, float ms[9]) {
 extern "C" int spp_msm_kernel_ms(spp_circuit* c, int which, float ms[7]) {
   if (!c || !ms) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
   HIP_TRY(hipSetDevice(c->ctx->device));
-  Workspace& w = c->ws[which ? c->last_ws ^ 1 : c->last_ws];
+  Workspace& w = c->ws[which ? c->prev_ws : c->last_ws];
   if (w.cap == 0) return fail(SPP_ERR_BAD_INPUT, "no such batch");
   HIP_TRY(hipStreamSynchronize(w.st));
   HIP_TRY(hipStreamSynchronize(w.st2));
@@ -1451,7 +1469,7 @@ extern "C" int spp_set_serial(spp_circuit* c, int on) {
   std::lock_guard<std::mutex> lk(c->ctx->mu);
   HIP_TRY(hipSetDevice(c->ctx->device));
   HIP_TRY(hipDeviceSynchronize());
-  for (int k = 0; k < 2; k++) {
+  for (int k = 0; k < SPP_NWS; k++) {
     Workspace& w = c->ws[k];
     w.st = on ? c->ws[0].own_st : w.own_st;
     w.st2 = on ? w.st : w.own_st2;
@@ -1508,7 +1526,9 @@ extern "C" int spp_prove_batch(spp_circuit* c, size_t count, const uint8_t* inpu
     }
     for (const auto& ch : chunks) {
       const size_t off = ch.first, n = ch.second;
+      if (c->next_ws >= 2) c->next_ws = 0;
       Workspace& w = c->ws[c->next_ws];
+      c->prev_ws = c->last_ws;
       c->last_ws = c->next_ws;
       c->next_ws ^= 1;
       if (int e = ensure_workspace(c, w, n)) return e;
@@ -1524,8 +1544,8 @@ extern "C" int spp_prove_batch(spp_circuit* c, size_t count, const uint8_t* inpu
     }
     if (prev_w)
       if (int e = fetch(*prev_w, prev_off, prev_n)) return e;
-    HIP_TRY(hipStreamSynchronize(c->ws[0].st));
-    HIP_TRY(hipStreamSynchronize(c->ws[1].st));
+    for (auto& w : c->ws)
+      if (w.st) HIP_TRY(hipStreamSynchronize(w.st));
   }
   int rc = SPP_OK;
   for (size_t i = 0; i < count; i++) {

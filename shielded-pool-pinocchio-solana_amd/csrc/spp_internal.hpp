@@ -128,11 +128,12 @@ inline hipError_t dev_upload(T** dst, const std::vector<T>& src) {
 // -----------------------------------------------------------------------------------------------------
 // context / circuit objects
 // -----------------------------------------------------------------------------------------------------
+static constexpr int SPP_NWS = 4;   // batch workspaces / proving streams per circuit (big batches use two)
 struct spp_ctx {
   int device;
   hipStream_t stream;        // setup / table construction
-  hipStream_t pstream[2];    // proving: consecutive batches alternate, so the (latency-bound, few-wave) witness
-                             // solver of batch k+1 overlaps the MSMs of batch k
+  hipStream_t pstream[SPP_NWS];   // proving: consecutive batches take the streams in turn, so the (latency-bound, few-wave)
+                                  // witness solver of batch k+1 overlaps the MSMs of batch k; small batches use up to four
   std::mutex mu;
   // lazily created constants of the stand-alone witness kernels
   bool consts_ready = false;
@@ -140,6 +141,10 @@ struct spp_ctx {
   GkAffine* gk_table = nullptr;
   bool rlwe_ready = false;
   RlweDev rlwe{};              // NTT tables of the RLWE witness kernel (rlwe_ntt.hpp)
+  // temporaries of spp_audit_inputs_batch(_device), kept between calls (grow only): a hipFree per call would drain every
+  // stream of the device, the proving streams of the batch in flight included
+  void* audit_scratch = nullptr;
+  size_t audit_scratch_cap = 0;
   std::vector<void*> owned;
 };
 template <class T>

@@ -380,14 +380,36 @@ extern "C" int spp_poseidon2_sponge_batch(spp_ctx* ctx, size_t count, uint32_t n
 // -----------------------------------------------------------------------------------------------------
 // audit inputs end to end on the device: (sk, r, e1, e2) -> 3360-field rows for spp_prove_batch(_device)
 // -----------------------------------------------------------------------------------------------------
+namespace {
+struct ScratchPiece {
+  void* p = nullptr;
+  template <class T> T* as() { return (T*)p; }
+};
+}  // namespace
 static int audit_inputs_on_device(spp_ctx* ctx, const uint32_t* d_pk_a, const uint32_t* d_pk_b, uint32_t count, const uint8_t* d_sk,
                                   const int8_t* d_r, const int8_t* d_e1, const int8_t* d_e2, uint8_t* d_rows) {
   hipStream_t st = ctx->stream;
-  DevBuf xy, msg, c0, c1, k0, k1, packed, ct, wa;
-  HIP_TRY(xy.alloc((size_t)count * 64)); HIP_TRY(msg.alloc((size_t)count * 64));
-  HIP_TRY(c0.alloc((size_t)count * 64 * 4)); HIP_TRY(c1.alloc((size_t)count * 1024 * 4));
-  HIP_TRY(k0.alloc((size_t)count * 64 * 4)); HIP_TRY(k1.alloc((size_t)count * 1024 * 4));
-  HIP_TRY(packed.alloc((size_t)count * 157 * 32)); HIP_TRY(ct.alloc((size_t)count * 32)); HIP_TRY(wa.alloc((size_t)count * 32));
+  // one cached allocation carved into the temporaries (256-byte aligned pieces)
+  ScratchPiece xy, msg, c0, c1, k0, k1, packed, ct, wa;
+  {
+    const size_t sizes[9] = {(size_t)count * 64, (size_t)count * 64, (size_t)count * 64 * 4, (size_t)count * 1024 * 4, (size_t)count * 64 * 4,
+                             (size_t)count * 1024 * 4, (size_t)count * 157 * 32, (size_t)count * 32, (size_t)count * 32};
+    ScratchPiece* pieces[9] = {&xy, &msg, &c0, &c1, &k0, &k1, &packed, &ct, &wa};
+    size_t total = 0;
+    for (size_t sz : sizes) total += (sz + 255) / 256 * 256;
+    if (total > ctx->audit_scratch_cap) {
+      if (ctx->audit_scratch) HIP_TRY(hipFree(ctx->audit_scratch));
+      ctx->audit_scratch = nullptr;
+      ctx->audit_scratch_cap = 0;
+      HIP_TRY(hipMalloc(&ctx->audit_scratch, total));
+      ctx->audit_scratch_cap = total;
+    }
+    size_t off = 0;
+    for (int i = 0; i < 9; i++) {
+      pieces[i]->p = (uint8_t*)ctx->audit_scratch + off;
+      off += (sizes[i] + 255) / 256 * 256;
+    }
+  }
   launch_grumpkin_keygen(st, ctx->gk_table, d_sk, xy.as<uint8_t>(), count);                       // generate_audit.py:482
   launch_poseidon_hash(st, ctx->hc, xy.as<uint8_t>(), 2, wa.as<uint8_t>(), count);                 // wa_commitment
   launch_audit_msg(st, xy.as<uint8_t>(), msg.as<uint8_t>(), count);                                // :489-496
@@ -397,7 +419,7 @@ static int audit_inputs_on_device(spp_ctx* ctx, const uint32_t* d_pk_a, const ui
   launch_poseidon2_sponge(st, ctx->hc, packed.as<uint8_t>(), 157, ct.as<uint8_t>(), count);        // ct_commitment :587
   launch_audit_assemble(st, wa.as<uint8_t>(), ct.as<uint8_t>(), packed.as<uint8_t>(), d_sk, d_r, d_e1, d_e2, k0.as<int32_t>(),
                         k1.as<int32_t>(), d_rows, count);                                          // Prover.toml order :630-641
-  HIP_TRY(hipStreamSynchronize(st));   // temporaries are released on return
+  HIP_TRY(hipStreamSynchronize(st));   // the rows are complete when the call returns (the caller hands them to a proving stream)
   HIP_TRY(hipGetLastError());
   return SPP_OK;
 }

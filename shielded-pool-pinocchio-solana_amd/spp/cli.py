@@ -73,6 +73,8 @@ def main(argv=None):
     p = sub.add_parser("prove"); p.add_argument("files", nargs="+", help="<sppc> <pk> <Prover.toml>  |  <acir.json> <witness.gz> <sppc> <pk>")
     p.add_argument("--device", type=int, default=0)
     p.add_argument("--window", type=int, default=0)
+    p.add_argument("--rs", nargs=2, default=None, metavar=("R", "S"),
+                   help="blinding factors (parity runs only: the default draws fresh ones from the OS, as every real proof must)")
     x = sub.add_parser("execute"); x.add_argument("acir"); x.add_argument("toml"); x.add_argument("-o", "--out", default=None)
     v = sub.add_parser("verify"); v.add_argument("vk"); v.add_argument("proof"); v.add_argument("pw")
     a = ap.parse_args(argv)
@@ -160,8 +162,7 @@ def main(argv=None):
             c = ccs.load_ccs(ccs_path)
             system = ccs.decode_system(c)
             sppc = os.path.splitext(ccs_path)[0] + ".sppc"
-            if not os.path.exists(sppc):
-                ccs.to_sppc(system, c, sppc)
+            ccs.to_sppc(system, c, sppc)          # always from THIS .ccs: a stale container of another system must not be proved
             stack = acir.read_witness_stack(gz)
             public = acir.abi_input_row(acir.load_program(acir_path), stack)[:len(c.public) - 1]
             secret = {"__witness_%d" % k: v for k, v in stack.items()}
@@ -193,7 +194,7 @@ def main(argv=None):
         base = os.path.splitext(a.sppc)[0]
         ctx = Context(a.device)
         h = ctx.load_circuit(a.sppc, a.pk, a.window)
-        proofs, pws, status = h.prove_batch([row])
+        proofs, pws, status = h.prove_batch([row], None if a.rs is None else [(_num(a.rs[0]), _num(a.rs[1]))])
         h.close()
         ctx.close()
         if status[0] != 0:

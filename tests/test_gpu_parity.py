@@ -894,6 +894,44 @@ def test_cli_setup_prove_verify_on_gpu(tmp_path, withdraw_kat):
     assert cli.main(["setup", sppc, "--seed", "11" * 32]) == 0 and os.path.getmtime(base + ".pk") > t0          # hash mismatch -> redone
 
 
+def test_cli_audit_pipeline_on_gpu(tmp_path, rlwe_pk, withdraw_kat, capsys):
+    """audit_circuit/prove_audit.sh:74-111 through the spp CLI on the GPU: compile -> setup -> prove from the Prover.toml that
+    scripts/generate_audit.py:630-641 writes (the reference's own run: sk = 12345, Random(999)) -> verify -> hex dump; proof bytes
+    equal the oracle's under the same key and blinding; a Prover.toml with one quotient off by one is refused (exit 1)."""
+    import json
+    import random
+    from spp import cli, generate_proof_hex
+    from spp.proof_helper import audit_prover_toml
+    from oracle import rlwe, native
+    root = tmp_path
+    adir, wdir = root / "audit_circuit" / "target", root / "noir_circuit" / "target"
+    adir.mkdir(parents=True); wdir.mkdir(parents=True)
+    pkj = tmp_path / "rlwe_pk.json"
+    pkj.write_text(json.dumps({"a": ["0x%08x" % v for v in rlwe_pk["a"]], "b": ["0x%08x" % v for v in rlwe_pk["b"]]}))
+    sppc = str(adir / "rlwe_audit.sppc")
+    assert cli.main(["compile", "audit", "--rlwe-pk", str(pkj), "-o", sppc]) == 0
+    assert "nbConstraints=" in capsys.readouterr().out                     # what benchmark_all.py:646,664 parses
+    assert cli.main(["setup", sppc, "--seed", "21" * 32]) == 0
+    d = rlwe.audit_inputs(rlwe_pk["a"], rlwe_pk["b"], 12345, random.Random(999))
+    toml = root / "audit_circuit" / "Prover.toml"
+    toml.write_text(audit_prover_toml(d))
+    base = str(adir / "rlwe_audit")
+    assert cli.main(["prove", sppc, base + ".pk", str(toml), "--window", "8", "--rs", "77", "99"]) == 0
+    assert os.path.getsize(base + ".proof") == 388 and os.path.getsize(base + ".pw") == 76   # submit_audit.rs:18-21
+    assert cli.main(["verify", base + ".vk", base + ".proof", base + ".pw"]) == 0
+    rc, proof, pw = native.Prover(sppc, base + ".pk").prove(rlwe.audit_input_vector(d), 77, 99)
+    assert rc == 0 and open(base + ".proof", "rb").read() == proof and open(base + ".pw", "rb").read() == pw
+    bad = dict(d)
+    bad["k1"] = list(d["k1"]); bad["k1"][5] += 1
+    (root / "audit_circuit" / "Bad.toml").write_text(audit_prover_toml(bad))
+    assert cli.main(["prove", sppc, base + ".pk", str(root / "audit_circuit" / "Bad.toml"), "--window", "8"]) == 1
+    # the hex dump of client/generate-proof-hex.ts needs the withdraw pair as well
+    (wdir / "shielded_pool_verifier.proof").write_bytes(b"\x01" * 388)
+    (wdir / "shielded_pool_verifier.pw").write_bytes(b"\x02" * 172)
+    code, out, err = generate_proof_hex.render(str(root))
+    assert code == 0 and "3. AUDIT PROOF (hex):" in out and "0x" + proof.hex() in out and "0x" + pw.hex() in out
+
+
 def test_audit_inputs_pipeline_on_gpu(ctx, rlwe_pk):
     """(sk, r, e1, e2) -> full audit input rows on the device == the oracle's restatement of generate_audit.py:468-641."""
     from spp import witness
