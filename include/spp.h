@@ -212,6 +212,14 @@ int spp_audit_inputs_batch(spp_ctx* ctx, const uint32_t* pk_a, const uint32_t* p
 int spp_audit_inputs_batch_device(spp_ctx* ctx, const void* d_pk_a, const void* d_pk_b, size_t count, const void* d_sk, const void* d_r,
                                   const void* d_e1, const void* d_e2, void* d_rows);
 
+/* End to end on the device: audit proofs from the provers' raw secrets.  Replaces the whole of scripts/generate_audit.py:468-691
+ * for `count` instances -- keygen, wa_commitment, RLWE encryption with the public key (pk_a, pk_b: 1024 x u32 each), quotient
+ * witnesses, packing, ct_commitment (:468-641), then `nargo execute` + `sunspot prove` (:668-685, audit_circuit/prove_audit.sh:
+ * 74-95) -- without a host round trip: all pointers are device memory (sk count*32 B big-endian, r / e2 count*1024 int8,
+ * e1 count*64 int8, rs count*64 B), outputs as spp_prove_batch_device.  Asynchronous, pipelined like spp_prove_batch_device. */
+int spp_prove_audit_from_secrets_device(spp_circuit* c, size_t count, const void* d_pk_a, const void* d_pk_b, const void* d_sk, const void* d_r,
+                                        const void* d_e1, const void* d_e2, const void* d_rs, void* d_proofs, void* d_pws, void* d_status);
+
 /* Batched verification on the GPU (`sunspot verify` for many proofs against one key, the checks of the
  * deployed verifier withdraw.rs:63-90 / submit_audit.rs:41-54): proofs = count * 388 B, pws = count * pw_len B (host
  * buffers), ok[i] = 1 iff proof i verifies.  Same decisions as spp_verify; one lane per proof. kernel_ms (optional):

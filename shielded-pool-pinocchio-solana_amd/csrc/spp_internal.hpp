@@ -171,6 +171,10 @@ struct DevBuf {
   } while (0)
 
 
+// the audit input pipeline as stream-ordered work (spp_witness_api.cpp); used by spp_prove_audit_from_secrets_device
+size_t spp_audit_scratch_bytes(size_t count);
+int spp_audit_inputs_enqueue(spp_ctx* ctx, hipStream_t st, void* scratch, const uint32_t* d_pk_a, const uint32_t* d_pk_b, uint32_t count,
+                             const uint8_t* d_sk, const int8_t* d_r, const int8_t* d_e1, const int8_t* d_e2, uint8_t* d_rows);
 // lazily built per-context constants (spp_witness_api.cpp)
 int spp_ensure_ctx_consts(spp_ctx* ctx);   // Poseidon / Poseidon2 constants, Grumpkin window table
 int spp_ensure_rlwe(spp_ctx* ctx);         // NTT tables of the RLWE witness kernel

@@ -385,40 +385,60 @@ struct ScratchPiece {
   void* p = nullptr;
   template <class T> T* as() { return (T*)p; }
 };
+const size_t AUDIT_PIECES = 10;
+void audit_piece_sizes(size_t count, size_t sizes[AUDIT_PIECES]) {
+  const size_t v[AUDIT_PIECES] = {count * 64, count * 64, count * 64 * 4, count * 1024 * 4, count * 64 * 4, count * 1024 * 4, count * 157 * 32, count * 32,
+                                  count * 32, sizeof(RlwePkDev)};
+  for (size_t i = 0; i < AUDIT_PIECES; i++) sizes[i] = (v[i] + 255) / 256 * 256;
+}
 }  // namespace
-static int audit_inputs_on_device(spp_ctx* ctx, const uint32_t* d_pk_a, const uint32_t* d_pk_b, uint32_t count, const uint8_t* d_sk,
-                                  const int8_t* d_r, const int8_t* d_e1, const int8_t* d_e2, uint8_t* d_rows) {
-  hipStream_t st = ctx->stream;
-  // one cached allocation carved into the temporaries (256-byte aligned pieces)
-  ScratchPiece xy, msg, c0, c1, k0, k1, packed, ct, wa;
+size_t spp_audit_scratch_bytes(size_t count) {
+  size_t sizes[AUDIT_PIECES], total = 0;
+  audit_piece_sizes(count, sizes);
+  for (size_t sz : sizes) total += sz;
+  return total;
+}
+// Enqueues the whole input pipeline of scripts/generate_audit.py:468-641 on `st` (no synchronisation): the rows are complete
+// for whatever is enqueued on `st` next.  scratch: spp_audit_scratch_bytes(count) bytes of device memory that stay untouched
+// until those kernels have run.
+int spp_audit_inputs_enqueue(spp_ctx* ctx, hipStream_t st, void* scratch, const uint32_t* d_pk_a, const uint32_t* d_pk_b, uint32_t count,
+                             const uint8_t* d_sk, const int8_t* d_r, const int8_t* d_e1, const int8_t* d_e2, uint8_t* d_rows) {
+  ScratchPiece xy, msg, c0, c1, k0, k1, packed, ct, wa, pkhat;
   {
-    const size_t sizes[9] = {(size_t)count * 64, (size_t)count * 64, (size_t)count * 64 * 4, (size_t)count * 1024 * 4, (size_t)count * 64 * 4,
-                             (size_t)count * 1024 * 4, (size_t)count * 157 * 32, (size_t)count * 32, (size_t)count * 32};
-    ScratchPiece* pieces[9] = {&xy, &msg, &c0, &c1, &k0, &k1, &packed, &ct, &wa};
-    size_t total = 0;
-    for (size_t sz : sizes) total += (sz + 255) / 256 * 256;
-    if (total > ctx->audit_scratch_cap) {
-      if (ctx->audit_scratch) HIP_TRY(hipFree(ctx->audit_scratch));
-      ctx->audit_scratch = nullptr;
-      ctx->audit_scratch_cap = 0;
-      HIP_TRY(hipMalloc(&ctx->audit_scratch, total));
-      ctx->audit_scratch_cap = total;
-    }
-    size_t off = 0;
-    for (int i = 0; i < 9; i++) {
-      pieces[i]->p = (uint8_t*)ctx->audit_scratch + off;
-      off += (sizes[i] + 255) / 256 * 256;
+    size_t sizes[AUDIT_PIECES], off = 0;
+    audit_piece_sizes(count, sizes);
+    ScratchPiece* pieces[AUDIT_PIECES] = {&xy, &msg, &c0, &c1, &k0, &k1, &packed, &ct, &wa, &pkhat};
+    for (size_t i = 0; i < AUDIT_PIECES; i++) {
+      pieces[i]->p = (uint8_t*)scratch + off;
+      off += sizes[i];
     }
   }
+  if (int e = spp_ensure_rlwe(ctx)) return e;
+  RlweDev rd = ctx->rlwe;
+  rd.pk = pkhat.as<RlwePkDev>();   // the transformed public key of THIS call (calls in flight on other streams may use other keys)
   launch_grumpkin_keygen(st, ctx->gk_table, d_sk, xy.as<uint8_t>(), count);                       // generate_audit.py:482
   launch_poseidon_hash(st, ctx->hc, xy.as<uint8_t>(), 2, wa.as<uint8_t>(), count);                 // wa_commitment
   launch_audit_msg(st, xy.as<uint8_t>(), msg.as<uint8_t>(), count);                                // :489-496
-  if (int e = spp_ensure_rlwe(ctx)) return e;
-  launch_rlwe_witness(st, ctx->rlwe, d_pk_a, d_pk_b, d_r, d_e1, d_e2, msg.as<uint8_t>(), c0.as<uint32_t>(), c1.as<uint32_t>(), k0.as<int32_t>(),
+  launch_rlwe_witness(st, rd, d_pk_a, d_pk_b, d_r, d_e1, d_e2, msg.as<uint8_t>(), c0.as<uint32_t>(), c1.as<uint32_t>(), k0.as<int32_t>(),
                       k1.as<int32_t>(), packed.as<uint8_t>(), count);                              // :507-584
   launch_poseidon2_sponge(st, ctx->hc, packed.as<uint8_t>(), 157, ct.as<uint8_t>(), count);        // ct_commitment :587
   launch_audit_assemble(st, wa.as<uint8_t>(), ct.as<uint8_t>(), packed.as<uint8_t>(), d_sk, d_r, d_e1, d_e2, k0.as<int32_t>(),
                         k1.as<int32_t>(), d_rows, count);                                          // Prover.toml order :630-641
+  return SPP_OK;
+}
+static int audit_inputs_on_device(spp_ctx* ctx, const uint32_t* d_pk_a, const uint32_t* d_pk_b, uint32_t count, const uint8_t* d_sk,
+                                  const int8_t* d_r, const int8_t* d_e1, const int8_t* d_e2, uint8_t* d_rows) {
+  hipStream_t st = ctx->stream;
+  // temporaries kept between calls (grow only): a hipFree per call would drain every stream of the device
+  const size_t total = spp_audit_scratch_bytes(count);
+  if (total > ctx->audit_scratch_cap) {
+    if (ctx->audit_scratch) HIP_TRY(hipFree(ctx->audit_scratch));
+    ctx->audit_scratch = nullptr;
+    ctx->audit_scratch_cap = 0;
+    HIP_TRY(hipMalloc(&ctx->audit_scratch, total));
+    ctx->audit_scratch_cap = total;
+  }
+  if (int e = spp_audit_inputs_enqueue(ctx, st, ctx->audit_scratch, d_pk_a, d_pk_b, count, d_sk, d_r, d_e1, d_e2, d_rows)) return e;
   HIP_TRY(hipStreamSynchronize(st));   // the rows are complete when the call returns (the caller hands them to a proving stream)
   HIP_TRY(hipGetLastError());
   return SPP_OK;

@@ -91,6 +91,7 @@ def load_library():
     L.spp_poseidon2_sponge_batch.argtypes = [vp, sz, u32, cp, vp]
     L.spp_audit_inputs_batch.argtypes = [vp, vp, vp, sz, cp, vp, vp, vp, vp]
     L.spp_audit_inputs_batch_device.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp, vp]
+    L.spp_prove_audit_from_secrets_device.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.spp_shamir_reconstruct.argtypes = [vp, u32, vp, cp, sz, vp, vp]
     L.spp_rlwe_decrypt_batch.argtypes = [vp, vp, sz, vp, vp, vp]
     L.spp_ntt_fr.argtypes = [vp, vp, u32, i32]

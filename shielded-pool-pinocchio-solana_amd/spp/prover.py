@@ -186,6 +186,11 @@ class CircuitHandle:
         """All arguments are raw device pointers (ints), e.g. torch tensors' data_ptr()."""
         check(self.L.spp_prove_batch_device(self.h, count, d_inputs, d_rs, d_proofs, d_pws, d_status))
 
+    def prove_audit_from_secrets_device(self, count, d_pk_a, d_pk_b, d_sk, d_r, d_e1, d_e2, d_rs, d_proofs, d_pws, d_status):
+        """Audit proofs from (secret_key, r, e1, e2) resident on the device (spp_prove_audit_from_secrets_device): the input pipeline of
+        scripts/generate_audit.py:468-641 runs on the proving stream in front of the solver.  Raw device pointers (ints)."""
+        check(self.L.spp_prove_audit_from_secrets_device(self.h, count, d_pk_a, d_pk_b, d_sk, d_r, d_e1, d_e2, d_rs, d_proofs, d_pws, d_status))
+
     def sync(self):
         check(self.L.spp_sync(self.h))
 

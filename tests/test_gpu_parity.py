@@ -3,6 +3,10 @@ Bit-exact comparison everywhere (integer / byte work)."""
 import os
 import random
 import pytest
+try:
+    import torch  # noqa: F401  (before libspp: both must share ONE HIP runtime; torch's has to be loaded first)
+except Exception:  # pragma: no cover
+    torch = None
 
 pytestmark = pytest.mark.gpu
 
@@ -913,6 +917,7 @@ def test_cli_audit_pipeline_on_gpu(tmp_path, rlwe_pk, withdraw_kat, capsys):
     assert "nbConstraints=" in capsys.readouterr().out                     # what benchmark_all.py:646,664 parses
     assert cli.main(["setup", sppc, "--seed", "21" * 32]) == 0
     d = rlwe.audit_inputs(rlwe_pk["a"], rlwe_pk["b"], 12345, random.Random(999))
+    d["e1_sparse"] = d["e1"]                                               # the Prover.toml key (generate_audit.py:637)
     toml = root / "audit_circuit" / "Prover.toml"
     toml.write_text(audit_prover_toml(d))
     base = str(adir / "rlwe_audit")
@@ -943,6 +948,43 @@ def test_audit_inputs_pipeline_on_gpu(ctx, rlwe_pk):
         exp.append(rlwe.audit_input_vector(d))
     got = witness.audit_input_rows(ctx, rlwe_pk["a"], rlwe_pk["b"], sks, rs, e1s, e2s)
     assert got == exp
+
+
+def test_audit_proofs_from_secrets_on_the_device(ctx, audit_artifacts, rlwe_pk):
+    """spp_prove_audit_from_secrets_device: (secret_key, r, e1, e2) -> proof without leaving the device == the oracle's proof of the
+    oracle's restatement of scripts/generate_audit.py:468-641 for the same secrets; 70 instances, two calls in flight (each with its own
+    scratch and transformed public key) produce the same bytes."""
+    import numpy as np
+    import torch
+    from spp import workload
+    from oracle import native, rlwe
+    B_ = 70
+    dev = torch.device("cuda", 0)
+    sks, r8, e18, e28 = workload.audit_noise(500, B_)
+    up = lambda raw: torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+    d_a, d_b = up(np.asarray(rlwe_pk["a"], dtype=np.uint32).tobytes()), up(np.asarray(rlwe_pk["b"], dtype=np.uint32).tobytes())
+    d_sk = up(b"".join(int(v).to_bytes(32, "big") for v in sks))
+    d_r, d_e1, d_e2 = up(r8.tobytes()), up(e18.tobytes()), up(e28.tobytes())
+    rs_vals = [(101 * i + 7, 103 * i + 9) for i in range(B_)]
+    d_rs = up(b"".join(r.to_bytes(32, "big") + s.to_bytes(32, "big") for r, s in rs_vals))
+    h = ctx.load_circuit(audit_artifacts["sppc"], audit_artifacts["pk"], 6)
+    try:
+        outs = [(torch.zeros(388 * B_, dtype=torch.uint8, device=dev), torch.zeros(76 * B_, dtype=torch.uint8, device=dev),
+                 torch.ones(B_, dtype=torch.int32, device=dev)) for _ in range(2)]
+        for pr, pw, st in outs:
+            h.prove_audit_from_secrets_device(B_, d_a.data_ptr(), d_b.data_ptr(), d_sk.data_ptr(), d_r.data_ptr(), d_e1.data_ptr(), d_e2.data_ptr(),
+                                              d_rs.data_ptr(), pr.data_ptr(), pw.data_ptr(), st.data_ptr())
+        h.sync()
+        assert all(int(o[2].abs().sum().item()) == 0 for o in outs)
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        pb, wb = bytes(outs[0][0].cpu().numpy()), bytes(outs[0][1].cpu().numpy())
+    finally:
+        h.close()
+    orc = native.Prover(audit_artifacts["sppc"], audit_artifacts["pk"])
+    for i in (0, 33, 64, B_ - 1):
+        d = rlwe.audit_inputs(rlwe_pk["a"], rlwe_pk["b"], 12345 + 500 + i, random.Random(1000 + 500 + i))
+        rc, proof, pw = orc.prove(rlwe.audit_input_vector(d), *rs_vals[i])
+        assert rc == 0 and pb[388 * i:388 * (i + 1)] == proof and wb[76 * i:76 * (i + 1)] == pw, i
 
 
 def test_host_mirror_generate_proof_and_audit_proof(tmp_path, withdraw_artifacts, audit_artifacts, withdraw_kat, rlwe_pk):
