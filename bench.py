@@ -60,6 +60,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline circuit only (profiling runs)")
     ap.add_argument("--no-other-circuits", action="store_true", help="headline circuit with its own legs (rehearsal, end to end), none of the other circuits / configs")
+    ap.add_argument("--pair-leg-only", action="store_true", help="diagnostic: only the leg with both circuits resident")
     ap.add_argument("--ccs-leg-only", action="store_true", help="diagnostic: only the leg that proves the reference's own gnark R1CS")
     ap.add_argument("--no-single", action="store_true", help="skip the single-proof latency leg (keeps profiler per-kernel averages clean)")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the host-buffer (PCIe-inclusive) leg: its chunks overlap on two workspaces and would "
@@ -537,7 +538,27 @@ def main():
             assert spp.verify(open(vkp, "rb").read(), one_pr.cpu().numpy().tobytes(), one_pw.cpu().numpy().tobytes())
             lat = sorted(lat[2:])
             single = {"inputs": kat_name, "latency_ms_median": round(lat[len(lat) // 2], 3), "latency_ms_min": round(lat[0], 3),
-                      "proofs_per_s_at_batch_1": round(1e3 / lat[len(lat) // 2], 2), "blinding": "full-size r, s"}
+                      "proofs_per_s_at_batch_1": round(1e3 / lat[len(lat) // 2], 2), "blinding": "full-size r, s",
+                      "tables": "the throughput handle above (window_bits = 0: one table row per base, a pass per window, Horner combine)"}
+            # the same proof on the tables the drop-in helpers load (generateProof / generateAuditProof: window_bits = 8, one row per
+            # window, no passes, ~6 GB): the latency configuration
+            try:
+                h8 = ctx.load_circuit(sppc, pkp, 8)
+                lat8 = []
+                for _ in range(12):
+                    torch.cuda.synchronize()
+                    tl = time.perf_counter()
+                    h8.prove_batch_device(1, one_in.data_ptr(), one_rs.data_ptr(), one_pr.data_ptr(), one_pw.data_ptr(), one_st.data_ptr())
+                    h8.sync()
+                    lat8.append((time.perf_counter() - tl) * 1e3)
+                assert int(one_st.item()) == 0
+                lat8 = sorted(lat8[2:])
+                single["latency_ms_median_8bit_tables"] = round(lat8[len(lat8) // 2], 3)
+                single["table_bytes_8bit"] = h8.table_bytes
+                h8.close()
+            except spp.SppError as e:   # not enough HBM left beside the big tables
+                single["latency_ms_median_8bit_tables"] = None
+                single["latency_8bit_note"] = str(e)
 
         # the timed batches produced real proofs: every proof of the last pipelined batch through the batched GPU verifier,
         # two of them also through the host verifier
@@ -705,6 +726,93 @@ def main():
         h.close(); ctx.close()
         return res
 
+    def coresident_leg(Bp=2048, steps=10, warmup=3, budget=228e9):
+        """One GPU serving BOTH circuits: the reference's relayer submits an audit proof and a withdraw proof per withdrawal
+        (demo-frontend/app/api/relay/withdraw/route.ts:238-276).  The windows of both circuits' MSM sets are planned under ONE budget
+        (spp_plan_windows: the greedy chooser over the union of their sets), both handles stay loaded, a step = Bp audit proofs + Bp
+        withdraw proofs (distinct rows), their batches alternating on the handles' proving streams; value = pairs/s."""
+        tmp = tempfile.mkdtemp(prefix="spp_bench_pair_")
+        paths = {}
+        ctx = spp.Context(local_rank)
+        for name, cid in (("audit", 2), ("withdraw", 1)):
+            sppc, pkp, vkp = (os.path.join(tmp, name + "." + e) for e in ("sppc", "pk", "vk"))
+            spp.build_circuit(cid, sppc, aux=(list(rlwe_pk["a"]) + list(rlwe_pk["b"])) if cid == 2 else None)
+            ctx.setup(sppc, b"\x2a" * 32, pkp, vkp)
+            paths[name] = (sppc, pkp, vkp)
+        plans = ctx.plan_windows([paths["audit"][1], paths["withdraw"][1]], budget)
+        t0 = time.time()
+        hs = {"audit": ctx.load_circuit(paths["audit"][0], paths["audit"][1], bits=plans[0]),
+              "withdraw": ctx.load_circuit(paths["withdraw"][0], paths["withdraw"][1], bits=plans[1])}
+        load_s = time.time() - t0
+        rows = {"audit": workload.audit_rows(ctx, rlwe_pk["a"], rlwe_pk["b"], Bp), "withdraw": workload.withdraw_rows(ctx, Bp, seed=31)}
+        up = lambda raw: torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        rs_b = b"".join((1000003 * i + 17).to_bytes(32, "big") + (998244353 * i + 29).to_bytes(32, "big") for i in range(Bp))
+        d_rs = up(rs_b)
+        d_in = {k: up(v) for k, v in rows.items()}
+        outs = {k: [(torch.zeros(388 * Bp, dtype=torch.uint8, device=dev), torch.zeros(h.pw_len * Bp, dtype=torch.uint8, device=dev),
+                     torch.zeros(Bp, dtype=torch.int32, device=dev)) for _ in range(2)] for k, h in hs.items()}
+
+        def step(i):
+            for k in ("audit", "withdraw"):
+                pr, pw, st_ = outs[k][i & 1]
+                hs[k].prove_batch_device(Bp, d_in[k].data_ptr(), d_rs.data_ptr(), pr.data_ptr(), pw.data_ptr(), st_.data_ptr())
+        def sync():
+            for h in hs.values():
+                h.sync()
+            torch.cuda.synchronize()
+        for i in range(warmup):
+            step(i)
+        sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(warmup + i)
+        sync()
+        elapsed = time.perf_counter() - t0
+        verified = {}
+        for k, h in hs.items():
+            pr, pw, st_ = outs[k][(warmup + steps - 1) & 1]
+            assert int(st_.abs().sum().item()) == 0
+            pb, wb = pr.cpu().numpy().tobytes(), pw.cpu().numpy().tobytes()
+            ok = ctx.verify_batch(open(paths[k][2], "rb").read(), [pb[388 * i:388 * (i + 1)] for i in range(Bp)],
+                                  [wb[h.pw_len * i:h.pw_len * (i + 1)] for i in range(Bp)])
+            assert all(ok), "%s: %d proofs of the last batch do not verify" % (k, Bp - sum(ok))
+            verified[k] = Bp
+        # serialised probe per handle (one stream each, one after the other): the dispatches' own durations
+        alg_total, ms_total, per = 0.0, 0.0, {}
+        for k, h in hs.items():
+            h.set_serial(True)
+            km = None
+            for i in range(2):
+                pr, pw, st_ = outs[k][i & 1]
+                h.prove_batch_device(Bp, d_in[k].data_ptr(), d_rs.data_ptr(), pr.data_ptr(), pw.data_ptr(), st_.data_ptr())
+                h.sync()
+                km = h.msm_kernel_ms(0)
+            h.set_serial(False)
+            sizes = dict(zip(INFO_ORDER, h.msm_sizes()))
+            alg = sum(64 * sizes[s_] + 32 * sizes[s_] * Bp for s_ in SETS[:6])
+            ms = sum(km[:6])
+            alg_total += alg
+            ms_total += ms
+            per[k] = {"msm_windows": dict(zip(INFO_ORDER, h.msm_windows())), "table_bytes": h.table_bytes, "g1_msm_kernels_ms_serialised": round(ms, 3),
+                      "alg_bytes_g1_msm": int(alg)}
+        achieved = alg_total / (ms_total * 1e-3) / 1e9
+        res = {"metric": "pairs (one audit proof + one withdraw proof) per second", "value": round(Bp * steps / elapsed, 1), "unit": "pairs/s",
+               "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "warmup": warmup,
+               "config": {"workload": "audit_circuit and noir_circuit withdraw CO-RESIDENT on one GPU, %d distinct rows of each per step" % Bp,
+                          "pairs_per_step": Bp, "table_budget_bytes": budget, "table_bytes_total": sum(p_["table_bytes"] for p_ in per.values()),
+                          "circuits": per, "load_s": round(load_s, 2), "verified": "all proofs of the last batch of both circuits by spp_verify_batch"},
+               "roofline": {"bound": "hbm", "kernel": "k_msm_flat<Fq>", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                            "note": "algorithmic bytes of the 12 G1 table walks of a pair of batches / their serialised durations"}}
+        for h in hs.values():
+            h.close()
+        ctx.close()
+        torch.cuda.empty_cache()
+        return res
+
+    if args.pair_leg_only:
+        print(json.dumps({"audit_plus_withdraw_coresident": coresident_leg()}), flush=True)
+        return
     if args.ccs_leg_only:
         print(json.dumps({"withdraw_reference_gnark_r1cs": reference_r1cs_leg()}), flush=True)
         return
@@ -723,6 +831,10 @@ def main():
             extras["withdraw_reference_gnark_r1cs"] = reference_r1cs_leg()
         except Exception as e:   # noqa: BLE001
             extras["withdraw_reference_gnark_r1cs"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:
+            extras["audit_plus_withdraw_coresident"] = coresident_leg()
+        except Exception as e:   # noqa: BLE001
+            extras["audit_plus_withdraw_coresident"] = {"error": "%s: %s" % (type(e).__name__, e)}
         ctx = spp.Context(local_rank)
         extras["rlwe_witness_2p16"] = rlwe_leg(ctx, dev, rlwe_pk)
         extras["msm_g1_2p24"] = pippenger_leg(ctx)

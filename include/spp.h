@@ -99,6 +99,14 @@ int spp_setup(spp_ctx* ctx, const char* circuit_path, const uint8_t seed[32], co
 /* Loads R1CS + proving key, builds the window tables in HBM. window_bits in [4,16] = the same window for every MSM set;
  * 0 = per-set windows chosen greedily within env SPP_TABLE_BUDGET_GB (default 240) and 85 % of the free HBM, single-row tables walked once per window (16 bits = 16 additions per scalar); env SPP_SERIAL=1 (profiling aid) puts both batch workspaces and the G2 MSM on one stream. */
 int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const char* pk_path, int window_bits, spp_circuit** out);
+/* Several circuits on ONE GPU at the same time (the reference's relayer submits an audit proof AND a withdraw proof per withdrawal,
+ * demo-frontend/app/api/relay/withdraw/route.ts:238-276): plan the windows of all their MSM sets under one HBM budget, then load
+ * each circuit with its share.  sizes / bits: n_circuits x 7 in the order of spp_circuit_msm_sizes; spp_pk_msm_sizes reads the
+ * sizes from a proving-key file; both are host-only.  spp_load_circuit_with_windows = spp_load_circuit(window_bits = 0) with
+ * the planned bits instead of a budget of its own (single-row tables; the two commitment sets keep one row per window). */
+int spp_pk_msm_sizes(const char* pk_path, uint32_t sizes[7]);
+int spp_plan_windows(uint32_t n_circuits, const uint32_t* sizes, double budget_bytes, uint32_t* bits);
+int spp_load_circuit_with_windows(spp_ctx* ctx, const char* circuit_path, const char* pk_path, const uint32_t bits[7], spp_circuit** out);
 void spp_free_circuit(spp_circuit* c);
 /* info[0..7] = id, n_public (without the constant), n_secret, n_wires, n_constraints, domain_log, n_inputs, window_bits */
 int spp_circuit_info(const spp_circuit* c, uint32_t info[8]);

@@ -765,7 +765,56 @@ static void merge_point(std::vector<uint32_t>& wires, std::vector<Affine<F>>& pt
   pts.push_back(extra);
 }
 
+// Greedy split of an HBM budget over the throughput-layout (one table row per base) MSM sets of one OR SEVERAL circuits: start
+// every set at 6 bits and repeatedly widen the set whose next window bit removes the most mixed-addition work per extra byte
+// (a G2 addition is weighted 3 G1 additions, as measured); `fixed` sets keep their bits.  With several circuits the unit of work
+// is one proof of each (the relayer's pair: an audit proof and a withdraw proof per withdrawal,
+// demo-frontend/app/api/relay/withdraw/route.ts:238-276), so their sets simply compete in one list.
+namespace {
+struct PlanSet {
+  double n, esz, wgt;   // bases, bytes per table entry, weight of an addition (0: fixed)
+  bool flat;            // one row per base (else one row per window)
+  int bits;
+};
+double plan_bytes(const PlanSet& s, int cb) { return s.n * s.esz * (s.flat ? 1.0 : (double)msm_windows((uint32_t)cb)) * (double)(1u << (cb - 1)); }
+void plan_greedy(std::vector<PlanSet>& sets, double budget, int cmax) {
+  double used = 0;
+  for (auto& s : sets) used += plan_bytes(s, s.bits);
+  for (;;) {
+    int best = -1;
+    double best_gain = 0;
+    for (size_t i = 0; i < sets.size(); i++) {
+      const PlanSet& s = sets[i];
+      if (s.wgt == 0 || s.bits >= cmax || s.n == 0) continue;
+      const double extra = plan_bytes(s, s.bits + 1) - plan_bytes(s, s.bits);
+      if (used + extra > budget) continue;
+      const double saved = s.wgt * s.n * ((double)msm_windows((uint32_t)s.bits) - (double)msm_windows((uint32_t)s.bits + 1));
+      double gain = saved / extra;
+      if (saved <= 0) gain = 1e-30;   // a bit that does not change the window count yet may enable the next one
+      if (gain > best_gain) { best_gain = gain; best = (int)i; }
+    }
+    if (best < 0) break;
+    used += plan_bytes(sets[best], sets[best].bits + 1) - plan_bytes(sets[best], sets[best].bits);
+    sets[best].bits++;
+  }
+}
+const double PLAN_ESZ[7] = {64, 64, 64, 64, 64, 64, 128}, PLAN_WGT[7] = {1, 1, 1, 1, 0, 0, 3.0};   // A, B1, K, Z, CB, CS, B2
+}  // namespace
+
+static int load_circuit_impl(spp_ctx* ctx, const char* circuit_path, const char* pk_path, int window_bits, const uint32_t* forced_bits,
+                             spp_circuit** out);
 extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const char* pk_path, int window_bits, spp_circuit** out) {
+  return load_circuit_impl(ctx, circuit_path, pk_path, window_bits, nullptr, out);
+}
+extern "C" int spp_load_circuit_with_windows(spp_ctx* ctx, const char* circuit_path, const char* pk_path, const uint32_t bits[7],
+                                             spp_circuit** out) {
+  if (!bits) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  for (int s = 0; s < 7; s++)
+    if (bits[s] < 4 || bits[s] > 16) return fail(SPP_ERR_BAD_INPUT, "window bits %u of set %d outside [4,16]", bits[s], s);
+  return load_circuit_impl(ctx, circuit_path, pk_path, 0, bits, out);
+}
+static int load_circuit_impl(spp_ctx* ctx, const char* circuit_path, const char* pk_path, int window_bits, const uint32_t* forced_bits,
+                             spp_circuit** out) {
   if (!ctx || !circuit_path || !pk_path || !out) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
   if (window_bits != 0 && (window_bits < 4 || window_bits > 16)) return fail(SPP_ERR_BAD_INPUT, "window_bits %d outside [4,16]", window_bits);
   std::lock_guard<std::mutex> lk(ctx->mu);
@@ -801,45 +850,28 @@ extern "C" int spp_load_circuit(spp_ctx* ctx, const char* circuit_path, const ch
   {
     const double nset[7] = {(double)pk.A.size() + 2, (double)pk.B1.size() + 2, (double)pk.K.size() + 1, (double)pk.Z.size(),
                             (double)pk.CB.size(), (double)pk.CS.size(), (double)pk.B2.size() + 2};
-    const double esz[7] = {64, 64, 64, 64, 64, 64, 128}, wgt[7] = {1, 1, 1, 1, 0, 0, 3.0};
-    if (window_bits != 0) {
+    if (forced_bits) {           // spp_load_circuit_with_windows: the caller planned the windows (spp_plan_windows), throughput layout
+      for (int s = 0; s < 7; s++) {
+        cw[s] = forced_bits[s];
+        flat[s] = PLAN_WGT[s] != 0;
+      }
+    } else if (window_bits != 0) {
       for (int s = 0; s < 7; s++) cw[s] = (uint32_t)window_bits;
     } else {
       const char* fe = getenv("SPP_FLAT");
       const bool use_flat = !(fe && fe[0] == '0');
-      for (int s = 0; s < 7; s++) flat[s] = use_flat && wgt[s] != 0;
-      auto bytes = [&](int s, int cb) {
-        return nset[s] * esz[s] * (flat[s] ? 1.0 : (double)msm_windows((uint32_t)cb)) * (double)(1u << (cb - 1));
-      };
       size_t free_b = 0, total_b = 0;
       HIP_TRY(hipMemGetInfo(&free_b, &total_b));
       double budget = 240e9;
       if (const char* env = getenv("SPP_TABLE_BUDGET_GB")) budget = atof(env) * 1e9;
       budget = std::min(budget, 0.85 * (double)free_b);
-      const int cmax = use_flat ? 16 : 15;
-      int cur[7] = {6, 6, 6, 6, 9, 9, 6};
-      double used = 0;
-      for (int s = 0; s < 7; s++) used += bytes(s, cur[s]);
-      for (;;) {
-        int best = -1;
-        double best_gain = 0;
-        for (int s = 0; s < 7; s++) {
-          if (wgt[s] == 0 || cur[s] >= cmax) continue;
-          double extra = bytes(s, cur[s] + 1) - bytes(s, cur[s]);
-          if (used + extra > budget) continue;
-          double saved = wgt[s] * nset[s] * ((double)msm_windows((uint32_t)cur[s]) - (double)msm_windows((uint32_t)cur[s] + 1));
-          double gain = saved / extra;
-          if (saved <= 0) gain = 1e-30;   // a bit that does not change the window count yet may enable the next one
-          if (gain > best_gain) { best_gain = gain; best = s; }
-        }
-        if (best < 0) break;
-        used += bytes(best, cur[best] + 1) - bytes(best, cur[best]);
-        cur[best]++;
+      std::vector<PlanSet> sets;
+      for (int s = 0; s < 7; s++) {
+        flat[s] = use_flat && PLAN_WGT[s] != 0;
+        sets.push_back({nset[s], PLAN_ESZ[s], PLAN_WGT[s], flat[s], PLAN_WGT[s] != 0 ? 6 : 9});
       }
-      // a last bit that did not lower the window count buys nothing: give it back (14 -> 13 never happens: 19 < 20 windows)
-      for (int s = 0; s < 7; s++)
-        while (wgt[s] != 0 && cur[s] > 6 && msm_windows((uint32_t)cur[s]) == msm_windows((uint32_t)cur[s] - 1)) cur[s]--;
-      for (int s = 0; s < 7; s++) cw[s] = (uint32_t)cur[s];
+      plan_greedy(sets, budget, use_flat ? 16 : 15);
+      for (int s = 0; s < 7; s++) cw[s] = (uint32_t)sets[s].bits;
     }
     c->c_bits = cw[3];   // reported window = that of the largest set (Z)
   }
@@ -1165,6 +1197,33 @@ extern "C" int spp_circuit_msm_table_rows(const spp_circuit* c, uint32_t rows[7]
 extern "C" int spp_circuit_msm_sizes(const spp_circuit* c, uint32_t sizes[7]) {
   if (!c || !sizes) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
   sizes[0] = c->A.N; sizes[1] = c->B1.N; sizes[2] = c->K.N; sizes[3] = c->Z.N; sizes[4] = c->CB.N; sizes[5] = c->CS.N; sizes[6] = c->B2.N;
+  return SPP_OK;
+}
+
+// bases per MSM set of a proving key file, as spp_circuit_msm_sizes reports them after loading (A, B1, K, Z, CB, CS, B2): what
+// spp_plan_windows needs before anything is loaded
+extern "C" int spp_pk_msm_sizes(const char* pk_path, uint32_t sizes[7]) {
+  if (!pk_path || !sizes) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  std::vector<uint8_t> pkbuf;
+  PkFile pk;
+  if (!read_file(pk_path, pkbuf)) return fail(SPP_ERR_IO, "cannot read proving key %s", pk_path);
+  if (!parse_pk(pkbuf, pk)) return fail(SPP_ERR_FORMAT, "malformed proving key %s", pk_path);
+  sizes[0] = (uint32_t)pk.A.size() + 2; sizes[1] = (uint32_t)pk.B1.size() + 2; sizes[2] = (uint32_t)pk.K.size() + 1;
+  sizes[3] = (uint32_t)pk.Z.size(); sizes[4] = (uint32_t)pk.CB.size(); sizes[5] = (uint32_t)pk.CS.size(); sizes[6] = (uint32_t)pk.B2.size() + 2;
+  return SPP_OK;
+}
+// window bits for the sets of n_circuits circuits that are to live on one GPU TOGETHER: sizes / bits = n_circuits x 7 (the order
+// above); one greedy split of budget_bytes over the union of their sets (see plan_greedy).  Host only.
+extern "C" int spp_plan_windows(uint32_t n_circuits, const uint32_t* sizes, double budget_bytes, uint32_t* bits) {
+  if (!sizes || !bits || n_circuits == 0 || n_circuits > 16) return fail(SPP_ERR_BAD_INPUT, "bad argument");
+  std::vector<PlanSet> sets;
+  for (uint32_t k = 0; k < n_circuits; k++)
+    for (int s = 0; s < 7; s++) sets.push_back({(double)sizes[7 * k + s], PLAN_ESZ[s], PLAN_WGT[s], PLAN_WGT[s] != 0, PLAN_WGT[s] != 0 ? 6 : 9});
+  double floor_bytes = 0;
+  for (auto& ps : sets) floor_bytes += plan_bytes(ps, ps.bits);
+  if (floor_bytes > budget_bytes) return fail(SPP_ERR_BAD_INPUT, "the budget does not hold even 6-bit tables (%.1f GB needed)", floor_bytes / 1e9);
+  plan_greedy(sets, budget_bytes, 16);
+  for (size_t i = 0; i < sets.size(); i++) bits[i] = (uint32_t)sets[i].bits;
   return SPP_OK;
 }
 

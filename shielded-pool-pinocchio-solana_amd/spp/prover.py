@@ -46,8 +46,22 @@ class Context:
         assert len(seed32) == 32
         check(self.L.spp_setup(self.h, circuit_path.encode(), bytes(seed32), pk_path.encode(), vk_path.encode()))
 
-    def load_circuit(self, circuit_path, pk_path, window_bits=0):
-        return CircuitHandle(self, circuit_path, pk_path, window_bits)
+    def load_circuit(self, circuit_path, pk_path, window_bits=0, bits=None):
+        """bits: 7 planned window sizes (plan_windows) instead of window_bits / a budget of this circuit's own."""
+        return CircuitHandle(self, circuit_path, pk_path, window_bits, bits)
+
+    def plan_windows(self, pk_paths, budget_bytes=240e9):
+        """Window bits for circuits that are to be resident TOGETHER: one greedy split of the budget over the union of their MSM
+        sets (spp_plan_windows).  Returns one list of 7 per proving key, in the order of CircuitHandle.msm_sizes()."""
+        n = len(pk_paths)
+        sizes = (ctypes.c_uint32 * (7 * n))()
+        for k, path in enumerate(pk_paths):
+            one = (ctypes.c_uint32 * 7)()
+            check(self.L.spp_pk_msm_sizes(path.encode(), one))
+            sizes[7 * k:7 * k + 7] = list(one)
+        bits = (ctypes.c_uint32 * (7 * n))()
+        check(self.L.spp_plan_windows(n, sizes, float(budget_bytes), bits))
+        return [list(bits[7 * k:7 * k + 7]) for k in range(n)]
 
     def ntt(self, values, inverse=False):
         """values: list of ints (len 2^k) -> list of ints, natural order."""
@@ -113,11 +127,15 @@ class Context:
 
 
 class CircuitHandle:
-    def __init__(self, ctx, circuit_path, pk_path, window_bits=0):
+    def __init__(self, ctx, circuit_path, pk_path, window_bits=0, bits=None):
         self.ctx = ctx
         self.L = ctx.L
         h = ctypes.c_void_p()
-        check(self.L.spp_load_circuit(ctx.h, circuit_path.encode(), pk_path.encode(), int(window_bits), ctypes.byref(h)))
+        if bits is not None:
+            arr = (ctypes.c_uint32 * 7)(*[int(b) for b in bits])
+            check(self.L.spp_load_circuit_with_windows(ctx.h, circuit_path.encode(), pk_path.encode(), arr, ctypes.byref(h)))
+        else:
+            check(self.L.spp_load_circuit(ctx.h, circuit_path.encode(), pk_path.encode(), int(window_bits), ctypes.byref(h)))
         self.h = h
         info = (ctypes.c_uint32 * 8)()
         check(self.L.spp_circuit_info(self.h, info))

@@ -93,3 +93,56 @@ def test_withdraw_bench_configuration_matches_the_oracle(ctx, withdraw_artifacts
         rc, proof, pw = orc.prove(workload.row_ints(rows_b, n_in, i), *rs_vals[i])
         assert rc == 0 and pl[i] == proof and wl[i] == pw, i
     assert all(ctx.verify_batch(open(withdraw_artifacts["vk"], "rb").read(), pl, wl))
+
+
+def test_audit_and_withdraw_coresident_match_the_oracle(ctx, audit_artifacts, withdraw_artifacts, rlwe_pk):
+    """One GPU serving both circuits (the relayer's pair: demo-frontend/app/api/relay/withdraw/route.ts:238-276): the windows of
+    BOTH circuits' MSM sets are planned under one 240 GB budget (spp_plan_windows: a greedy split over the union of the sets),
+    both handles are loaded and prove alternating batches while co-resident; sampled proofs of each == the oracle's bytes, every
+    proof passes the batched verifier."""
+    from spp import workload
+    from oracle import native
+    plans = ctx.plan_windows([audit_artifacts["pk"], withdraw_artifacts["pk"]], 236e9)
+    ha = ctx.load_circuit(audit_artifacts["sppc"], audit_artifacts["pk"], bits=plans[0])
+    hw = None
+    try:
+        hw = ctx.load_circuit(withdraw_artifacts["sppc"], withdraw_artifacts["pk"], bits=plans[1])
+        assert ha.msm_windows() == plans[0] and hw.msm_windows() == plans[1]
+        assert ha.table_bytes + hw.table_bytes <= 236e9 and min(plans[0][:4] + plans[1][:4]) >= 13, (plans, ha.table_bytes, hw.table_bytes)
+        Ba, Bw = 512, 1024
+        rows_a = workload.audit_rows(ctx, rlwe_pk["a"], rlwe_pk["b"], Ba, first=7000)
+        rows_w = workload.withdraw_rows(ctx, Bw, seed=77)
+        rs_a, rsb_a = _blinding(Ba, 11)
+        rs_w, rsb_w = _blinding(Bw, 12)
+        dev = torch.device("cuda", 0)
+        up = lambda raw: torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        bufs = {}
+        for name, h, rows, rsb, B in (("a", ha, rows_a, rsb_a, Ba), ("w", hw, rows_w, rsb_w, Bw)):
+            bufs[name] = (up(rows), up(rsb), torch.zeros(388 * B, dtype=torch.uint8, device=dev), torch.zeros(h.pw_len * B, dtype=torch.uint8, device=dev),
+                          torch.ones(B, dtype=torch.int32, device=dev))
+        for _ in range(2):   # alternating batches, all in flight together
+            for name, h, B in (("a", ha, Ba), ("w", hw, Bw)):
+                i_, r_, p_, w_, s_ = bufs[name]
+                h.prove_batch_device(B, i_.data_ptr(), r_.data_ptr(), p_.data_ptr(), w_.data_ptr(), s_.data_ptr())
+        ha.sync(); hw.sync()
+        res = {}
+        for name, h, B in (("a", ha, Ba), ("w", hw, Bw)):
+            _, _, p_, w_, s_ = bufs[name]
+            assert int(s_.abs().sum().item()) == 0
+            pb, wb = bytes(p_.cpu().numpy()), bytes(w_.cpu().numpy())
+            res[name] = ([pb[388 * i:388 * (i + 1)] for i in range(B)], [wb[h.pw_len * i:h.pw_len * (i + 1)] for i in range(B)])
+        na, nw = ha.n_inputs, hw.n_inputs
+    finally:
+        ha.close()
+        if hw is not None:
+            hw.close()
+    orc_a = native.Prover(audit_artifacts["sppc"], audit_artifacts["pk"])
+    orc_w = native.Prover(withdraw_artifacts["sppc"], withdraw_artifacts["pk"])
+    for i in (0, 255, Ba - 1):
+        rc, proof, pw = orc_a.prove(workload.row_ints(rows_a, na, i), *rs_a[i])
+        assert rc == 0 and res["a"][0][i] == proof and res["a"][1][i] == pw, ("audit", i)
+    for i in (0, 64, 513, Bw - 1):
+        rc, proof, pw = orc_w.prove(workload.row_ints(rows_w, nw, i), *rs_w[i])
+        assert rc == 0 and res["w"][0][i] == proof and res["w"][1][i] == pw, ("withdraw", i)
+    assert all(ctx.verify_batch(open(audit_artifacts["vk"], "rb").read(), *res["a"]))
+    assert all(ctx.verify_batch(open(withdraw_artifacts["vk"], "rb").read(), *res["w"]))
