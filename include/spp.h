@@ -117,6 +117,9 @@ int spp_circuit_msm_windows(const spp_circuit* c, uint32_t bits[7]);
 /* table rows per base of each of those sets (same order): 1 = one row of 2^(bits-1) multiples, walked once per window
  * (the throughput layout chosen with window_bits = 0); ceil(254 / bits) = one row per window (explicit window_bits) */
 int spp_circuit_msm_table_rows(const spp_circuit* c, uint32_t rows[7]);
+/* out[0] = rows of A / B / C that the matrix evaluation sums in integer arithmetic (every term a small coefficient times a wire the
+ * lookup argument bounds to a byte range: the audit circuit's 1 088 quotient equations), out[1] = such wires (+1: the constant) */
+int spp_circuit_small_rows(const spp_circuit* c, uint32_t out[2]);
 /* exact bytes of HBM held by the window tables */
 uint64_t spp_circuit_table_bytes(const spp_circuit* c);
 

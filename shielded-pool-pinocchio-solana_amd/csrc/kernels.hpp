@@ -40,6 +40,20 @@ struct DevCircuit {
   // identical to the B row (a square).  A solver lane that has just evaluated row k - 1 reuses the value instead of walking
   // the same linear form again: the rows of a power map share their B side, and compiled (ACIR) circuits have long forms.
   const uint8_t* row_flags;
+  // "small rows" of the matrix evaluation (spp_api.cpp, small_rows_plan): rows whose every term is a small integer coefficient
+  // times a wire that the lookup argument bounds to a byte-sized range (the audit circuit's 1 088 quotient equations: 1 024
+  // public-key coefficients < 2^28 times noise values in [-3, 3], generate_audit.py:57-66,236-243, plus ciphertext bytes).  The
+  // bounded wires are extracted once per batch as int16 (k_small_extract), the rows are summed as 64-bit integers
+  // (k_spmv_small_rows) and land in the a / b / c arrays before k_spmv_check runs, which then skips them (row_small bits).
+  const uint32_t* sm_wires;     // wire of small slot s (slot 0 = wire 0, the constant one)
+  const int32_t* sm_lo;         // lowest value the lookup argument allows for slot s (highest = lo + 255)
+  uint32_t sm_nslots;
+  const uint32_t* sm_rowptr;    // per small row: terms [rowptr[r], rowptr[r+1])
+  const uint32_t* sm_slot;      // slot of a term
+  const int32_t* sm_coef;       // its coefficient
+  const uint32_t* sm_row_out;   // matrix (0 = A, 1 = B, 2 = C) << 30 | constraint
+  uint32_t sm_nrows;
+  const uint8_t* row_small;     // per constraint: bit 0 A, bit 1 B, bit 2 C is a small row (nullptr: none)
   // hash constants (Montgomery)
   const Fr* pos3_rc;  const Fr* pos3_mds;   // t=3: 195 rc, 9 mds (row-major)
   const Fr* pos5_rc;  const Fr* pos5_mds;   // t=5: 340 rc, 25 mds
@@ -135,7 +149,8 @@ void launch_verify(hipStream_t st, const VerifyKeyDev* vk, const uint8_t* proofs
                    int32_t* ok);
 struct PairingCheckDev;
 void launch_pairing_check(hipStream_t st, const PairingCheckDev* a, int32_t* ok);
-void launch_spmv_check(hipStream_t st, DevCircuit dc, const Fr* W, Fr* abc, uint32_t n, uint32_t P, uint32_t* status);
+// small: [sm_nslots][P] int16 scratch of the small rows (may be nullptr when the circuit has none)
+void launch_spmv_check(hipStream_t st, DevCircuit dc, const Fr* W, Fr* abc, uint32_t n, uint32_t P, uint32_t* status, int16_t* small = nullptr);
 
 // ---- NTT / QAP ----
 // in-place radix-2 passes over data [n][P]; dif: natural->bitreversed with table tw (w^-k or w^k), else DIT

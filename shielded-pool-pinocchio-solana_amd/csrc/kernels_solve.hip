@@ -777,6 +777,42 @@ __device__ __forceinline__ Fr dev_row_dot_wide(const DevSparse& m, const Fr* __r
   return acc;
 }
 
+// ---- small rows (see DevCircuit) --------------------------------------------------------------------------------------------
+// slot s, proof p: the wire's value as a small signed integer.  A value outside the range the lookup argument allows cannot
+// satisfy the circuit (its lookup row fails): the proof is refused here already, and the rows built on it may hold anything.
+__global__ void __launch_bounds__(256) k_small_extract(DevCircuit dc, const Fr* __restrict__ W, int16_t* __restrict__ small, uint32_t P,
+                                                       uint32_t* __restrict__ status) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (uint64_t)dc.sm_nslots * P) return;
+  const uint32_t p = (uint32_t)(g % P), s = (uint32_t)(g / P);
+  uint32_t c[8], n[8];
+  W[(size_t)dc.sm_wires[s] * P + p].to_canonical(c);
+  canonical_negate<FrParams>(c, n);
+  const bool pos = (c[1] | c[2] | c[3] | c[4] | c[5] | c[6] | c[7]) == 0 && c[0] < 32768u;
+  const bool neg = (n[1] | n[2] | n[3] | n[4] | n[5] | n[6] | n[7]) == 0 && n[0] <= 32768u && (c[0] | c[1] | c[2] | c[3] | c[4] | c[5] | c[6] | c[7]) != 0;
+  int v = pos ? (int)c[0] : neg ? -(int)n[0] : 0;
+  const int lo = dc.sm_lo[s];
+  if ((!pos && !neg) || v < lo || v > lo + 255) {
+    atomicOr(&status[p], 1u);
+    v = 0;
+  }
+  small[g] = (int16_t)v;
+}
+// small row r, proof p: sum of coefficient * small value as a 64-bit integer (|sum| < 2^31 * 2^15 * terms), stored as a field
+// element where k_spmv_check expects the row's value
+__global__ void __launch_bounds__(256) k_spmv_small_rows(DevCircuit dc, const int16_t* __restrict__ small, Fr* __restrict__ abc, uint32_t n,
+                                                         uint32_t P) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (uint64_t)dc.sm_nrows * P) return;
+  const uint32_t p = (uint32_t)(g % P), r = (uint32_t)(g / P);
+  const uint32_t b = dc.sm_rowptr[r], e = dc.sm_rowptr[r + 1];
+  long long acc = 0;
+  for (uint32_t t = b; t < e; t++) acc += (long long)dc.sm_coef[t] * (long long)small[(size_t)dc.sm_slot[t] * P + p];
+  const uint32_t ro = dc.sm_row_out[r], mat = ro >> 30, k = ro & 0x3fffffffu;
+  const Fr mag = Fr::from_u64((uint64_t)(acc < 0 ? -acc : acc));
+  abc[(size_t)mat * n * P + (size_t)k * P + p] = acc < 0 ? mag.neg() : mag;
+}
+
 // lane -> (run r of constraints with one shared B row, proof p); lanes past the last run zero-fill the padding rows
 // n_constraints .. n-1 of the evaluation domain
 __global__ void __launch_bounds__(256) k_spmv_check(DevCircuit dc, const Fr* __restrict__ W, Fr* __restrict__ abc, uint32_t n, uint32_t P,
@@ -794,13 +830,16 @@ __global__ void __launch_bounds__(256) k_spmv_check(DevCircuit dc, const Fr* __r
     return;
   }
   const uint32_t k0 = dc.run_start[r], k1 = dc.run_start[r + 1];
-  const Fr b = dev_row_dot_wide(dc.B, dc.coeffs, k0, W, P, p);
+  const uint8_t* __restrict__ rs = dc.row_small;
+  // the rows of a run share their B row; a small B row was stored for the run's first constraint by k_spmv_small_rows
+  const Fr b = (rs && (rs[k0] & 2)) ? abc[total + (uint64_t)k0 * P + p] : dev_row_dot_wide(dc.B, dc.coeffs, k0, W, P, p);
   bool bad = false;
   for (uint32_t k = k0; k < k1; k++) {
-    const Fr a = dev_row_dot_wide(dc.A, dc.coeffs, k, W, P, p);
-    const Fr c = dev_row_dot_wide(dc.C, dc.coeffs, k, W, P, p);
-    bad |= (a * b != c);
     const uint64_t o = (uint64_t)k * P + p;
+    const uint32_t f = rs ? rs[k] : 0u;
+    const Fr a = (f & 1) ? abc[o] : dev_row_dot_wide(dc.A, dc.coeffs, k, W, P, p);
+    const Fr c = (f & 4) ? abc[2 * total + o] : dev_row_dot_wide(dc.C, dc.coeffs, k, W, P, p);
+    bad |= (a * b != c);
     abc[o] = a;
     abc[total + o] = b;
     abc[2 * total + o] = c;
@@ -843,13 +882,20 @@ __global__ void __launch_bounds__(256) k_spmv_check_rows(DevCircuit dc, const Fr
   abc[total + e] = b;
   abc[2 * total + e] = c;
 }
-void launch_spmv_check(hipStream_t st, DevCircuit dc, const Fr* W, Fr* abc, uint32_t n, uint32_t P, uint32_t* status) {
+void launch_spmv_check(hipStream_t st, DevCircuit dc, const Fr* W, Fr* abc, uint32_t n, uint32_t P, uint32_t* status, int16_t* small) {
   // circuits with long rows, up to 64 proofs: with 16 lanes per row the longest row is what a small batch waits for (audit: 0.3 ms +
   // 33 us per proof against 4.4 ms for the run kernel's single lane on the 6 720-term row; measured equal near 128 proofs)
   if ((uint64_t)dc.n_runs * P < 65536 || (P <= 64 && dc.max_row_terms > 1024)) {
     const uint64_t lanes = (uint64_t)n * P * SPMV_G;
     hipLaunchKernelGGL(k_spmv_check_rows, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, st, dc, W, abc, n, P, status);
     return;
+  }
+  if (small && dc.sm_nrows) {
+    const uint64_t l1 = (uint64_t)dc.sm_nslots * P, l2 = (uint64_t)dc.sm_nrows * P;
+    hipLaunchKernelGGL(k_small_extract, dim3((uint32_t)((l1 + 255) / 256)), dim3(256), 0, st, dc, W, small, P, status);
+    hipLaunchKernelGGL(k_spmv_small_rows, dim3((uint32_t)((l2 + 255) / 256)), dim3(256), 0, st, dc, small, abc, n, P);
+  } else {
+    dc.row_small = nullptr;
   }
   const uint64_t lanes = (uint64_t)(dc.n_runs + (n - dc.n_constraints)) * P;
   hipLaunchKernelGGL(k_spmv_check, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, st, dc, W, abc, n, P, status);

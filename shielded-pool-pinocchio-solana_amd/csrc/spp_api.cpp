@@ -45,6 +45,7 @@ struct Workspace {
   // other on `st`; the G2 set runs beside them on the side stream and has its own
   int16_t *dig1 = nullptr, *dig2 = nullptr;
   size_t dig1_cap = 0, dig2_cap = 0;
+  int16_t* small = nullptr;           // [sm_nslots][P]: byte-ranged wires as integers (small rows of the matrix evaluation)
   void* audit_scratch = nullptr;      // temporaries of the audit input pipeline (spp_prove_audit_from_secrets_device), P = cap
   size_t audit_scratch_cap = 0;
   std::vector<void*> owned;
@@ -469,6 +470,101 @@ static int coop_plan(spp_circuit* c) {
       (e = own_upload(c, &d_lr, lvl_rows)) || (e = own_upload(c, &d_ls, stream)))
     return e;
   c->coop.items = d_items; c->coop.par = d_par; c->coop.lvl_ptr = d_lp; c->coop.lvl_rows = d_lr; c->coop.lvl_stream = d_ls;
+  return 0;
+}
+
+// Small rows of the matrix evaluation (DevCircuit::sm_*).  A wire is "byte-ranged" when one of the looked-up values of an OP_COUNT8
+// range check is exactly that wire, or that wire plus a small constant: the log-derivative argument then holds only if the wire's
+// value lies in [-c, 255 - c].  A row of A, B or C with at least SMALL_ROW_MIN terms, all of them (small integer coefficient) x
+// (byte-ranged wire or the constant one), is evaluated in 64-bit integer arithmetic from an int16 copy of those wires: the audit
+// circuit's 1 088 quotient equations (1 024 public-key coefficients each) are 1.13 M of the 1.8 M matrix terms of a proof, and
+// re-read the same 1 024 witness rows 1 088 times -- 73 GB of L2 misses per 2 048-proof batch in the general kernel (20 ms,
+// profiles/round2_audit_b2048_pmc_hbm.json); as integers over a 13 MB array they take well under a millisecond.
+// SPP_NO_SMALL_ROWS=1 (diagnostic): off.
+static constexpr uint32_t SMALL_ROW_MIN = 64;
+static int small_rows_plan(spp_circuit* c) {
+  const Circuit& circ = c->circ;
+  c->dc.sm_nrows = 0;
+  c->dc.sm_nslots = 0;
+  c->dc.row_small = nullptr;
+  if (getenv("SPP_NO_SMALL_ROWS")) return 0;
+  // signed small value of a coefficient-table entry, if it has one
+  auto small_of = [&](uint32_t ci, int64_t* out) {
+    uint32_t v[8];
+    circ.coeffs[ci].to_canonical(v);
+    bool hi0 = true;
+    for (int k = 1; k < 8; k++) hi0 = hi0 && v[k] == 0;
+    if (hi0 && v[0] < (1u << 30)) { *out = (int64_t)v[0]; return true; }
+    circ.coeffs[ci].neg().to_canonical(v);
+    hi0 = true;
+    for (int k = 1; k < 8; k++) hi0 = hi0 && v[k] == 0;
+    if (hi0 && v[0] < (1u << 30)) { *out = -(int64_t)v[0]; return true; }
+    return false;
+  };
+  std::vector<int32_t> slot_of(circ.n_wires, -1);
+  std::vector<uint32_t> wires{0};
+  std::vector<int32_t> lo{0};
+  slot_of[0] = 0;   // the constant one
+  for (const SolveStep& st : c->schedule) {
+    if (st.kind != SolveStep::COUNT8) continue;
+    for (uint32_t h = st.a; h < st.a + st.b && h < circ.H.rows(); h++) {
+      uint32_t w = 0, nw = 0;
+      int64_t cst = 0;
+      bool ok = true;
+      for (uint32_t t = circ.H.rowptr[h]; t < circ.H.rowptr[h + 1] && ok; t++) {
+        const Term& tm = circ.H.terms[t];
+        int64_t v;
+        if (!small_of(tm.coeff, &v)) { ok = false; break; }
+        if (tm.wire == 0) cst += v;
+        else if (v == 1) { w = tm.wire; nw++; }
+        else ok = false;
+      }
+      if (!ok || nw != 1 || cst < -32000 || cst > 32000 || slot_of[w] >= 0) continue;
+      slot_of[w] = (int32_t)wires.size();
+      wires.push_back(w);
+      lo.push_back((int32_t)-cst);
+    }
+  }
+  if (wires.size() < 2) return 0;
+  std::vector<uint32_t> rowptr{0}, slots, row_out;
+  std::vector<int32_t> coefs;
+  std::vector<uint8_t> flags(std::max<uint32_t>(circ.n_constraints, 1), 0);
+  const Sparse* mats[3] = {&circ.A, &circ.B, &circ.C};
+  for (uint32_t mi = 0; mi < 3; mi++) {
+    const Sparse& m = *mats[mi];
+    for (uint32_t k = 0; k < circ.n_constraints; k++) {
+      const uint32_t b = m.rowptr[k], e = m.rowptr[k + 1];
+      if (e - b < SMALL_ROW_MIN || e - b > (1u << 20)) continue;
+      bool ok = true;
+      for (uint32_t t = b; t < e && ok; t++) {
+        int64_t v;
+        ok = slot_of[m.terms[t].wire] >= 0 && small_of(m.terms[t].coeff, &v);
+      }
+      if (!ok) continue;
+      for (uint32_t t = b; t < e; t++) {
+        int64_t v = 0;
+        small_of(m.terms[t].coeff, &v);
+        slots.push_back((uint32_t)slot_of[m.terms[t].wire]);
+        coefs.push_back((int32_t)v);
+      }
+      rowptr.push_back((uint32_t)slots.size());
+      row_out.push_back((mi << 30) | k);
+      flags[k] |= (uint8_t)(1u << mi);
+    }
+  }
+  if (row_out.empty()) return 0;
+  // a run of constraints shares ONE B evaluation (its first row's): the flag of the first row decides for the run, and the rows of
+  // a run have identical B rows, so they qualify together
+  uint32_t *d_w, *d_rp, *d_sl, *d_ro;
+  int32_t *d_lo, *d_co;
+  uint8_t* d_fl;
+  int e;
+  if ((e = own_upload(c, &d_w, wires)) || (e = own_upload(c, &d_lo, lo)) || (e = own_upload(c, &d_rp, rowptr)) || (e = own_upload(c, &d_sl, slots)) ||
+      (e = own_upload(c, &d_co, coefs)) || (e = own_upload(c, &d_ro, row_out)) || (e = own_upload(c, &d_fl, flags)))
+    return e;
+  c->dc.sm_wires = d_w; c->dc.sm_lo = d_lo; c->dc.sm_nslots = (uint32_t)wires.size();
+  c->dc.sm_rowptr = d_rp; c->dc.sm_slot = d_sl; c->dc.sm_coef = d_co; c->dc.sm_row_out = d_ro; c->dc.sm_nrows = (uint32_t)row_out.size();
+  c->dc.row_small = d_fl;
   return 0;
 }
 
@@ -1031,6 +1127,7 @@ static int load_circuit_impl(spp_ctx* ctx, const char* circuit_path, const char*
   }
 
   if (int e = coop_plan(c)) return e;
+  if (int e = small_rows_plan(c)) return e;
 
   // ---- NTT tables ----
   {
@@ -1184,6 +1281,12 @@ extern "C" int spp_circuit_info(const spp_circuit* c, uint32_t info[8]) {
   return SPP_OK;
 }
 extern "C" uint64_t spp_circuit_table_bytes(const spp_circuit* c) { return c ? c->table_bytes : 0; }
+extern "C" int spp_circuit_small_rows(const spp_circuit* c, uint32_t out[2]) {
+  if (!c || !out) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  out[0] = c->dc.sm_nrows;
+  out[1] = c->dc.sm_nslots;
+  return SPP_OK;
+}
 extern "C" int spp_circuit_msm_windows(const spp_circuit* c, uint32_t bits[7]) {
   if (!c || !bits) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
   bits[0] = c->A.c; bits[1] = c->B1.c; bits[2] = c->K.c; bits[3] = c->Z.c; bits[4] = c->CB.c; bits[5] = c->CS.c; bits[6] = c->B2.c;
@@ -1274,6 +1377,7 @@ static int ensure_workspace(spp_circuit* c, Workspace& w, size_t P) {
     w.dig1_cap = d1;
     w.dig2_cap = msm_digit_elems(c->B2.N, (uint32_t)P, c->B2.c);
     if ((e = ws_alloc(w, &w.dig1, w.dig1_cap)) || (e = ws_alloc(w, &w.dig2, w.dig2_cap))) return e;
+    if (c->dc.sm_nrows && (e = ws_alloc(w, &w.small, (size_t)c->dc.sm_nslots * P))) return e;
   }
   w.cap = P;
   return 0;
@@ -1354,7 +1458,7 @@ static int prove_on_device(spp_circuit* c, Workspace& w, uint32_t P, const uint8
   run_msm(c, w, c->B2, w.B2, P, false, side, &w.g2_ev);
   hipEventRecord(w.ev_b2, side);
   // 2. constraint evaluations + satisfaction check
-  launch_spmv_check(st, c->dc, w.W, w.abc, n, P, d_status);
+  launch_spmv_check(st, c->dc, w.W, w.abc, n, P, d_status, w.small);
   hipEventRecord(w.ev[2], st);
   // 3. h = (a*b - c)/Z  (coefficients land bit-reversed in the a-slot of abc)
   const size_t bs = (size_t)n * P;

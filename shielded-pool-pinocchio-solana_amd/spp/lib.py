@@ -57,6 +57,7 @@ def load_library():
     L.spp_circuit_msm_sizes.argtypes = [vp, ctypes.POINTER(u32)]
     L.spp_circuit_msm_windows.argtypes = [vp, ctypes.POINTER(u32)]
     L.spp_circuit_msm_table_rows.argtypes = [vp, ctypes.POINTER(u32)]
+    L.spp_circuit_small_rows.argtypes = [vp, ctypes.POINTER(u32)]
     L.spp_pk_msm_sizes.argtypes = [cp, ctypes.POINTER(u32)]
     L.spp_plan_windows.argtypes = [u32, ctypes.POINTER(u32), ctypes.c_double, ctypes.POINTER(u32)]
     L.spp_load_circuit_with_windows.argtypes = [vp, cp, cp, ctypes.POINTER(u32), ctypes.POINTER(vp)]

@@ -158,6 +158,12 @@ class CircuitHandle:
         check(self.L.spp_circuit_msm_windows(self.h, s))
         return list(s)
 
+    def small_rows(self):
+        """(rows of the matrix evaluation summed as integers, byte-ranged wires they read) -- spp_circuit_small_rows"""
+        s = (ctypes.c_uint32 * 2)()
+        check(self.L.spp_circuit_small_rows(self.h, s))
+        return list(s)
+
     def msm_table_rows(self):
         """table rows per base and set: 1 = single-row tables walked once per window (window_bits = 0)"""
         s = (ctypes.c_uint32 * 7)()

@@ -307,6 +307,8 @@ def test_batch_of_distinct_audit_rows(ctx, audit_artifacts, rlwe_pk):
     h = ctx.load_circuit(audit_artifacts["sppc"], audit_artifacts["pk"], 6)
     try:
         import ctypes
+        # the 1 088 quotient equations (generate_audit.py:539-554) take the integer path of the matrix evaluation
+        assert h.small_rows()[0] == 1088 and h.small_rows()[1] > 2112
         rs = b"".join((31 * i + 3).to_bytes(32, "big") + (37 * i + 5).to_bytes(32, "big") for i in range(B_))
         proofs = ctypes.create_string_buffer(388 * B_)
         pws = ctypes.create_string_buffer(h.pw_len * B_)
@@ -327,6 +329,42 @@ def test_batch_of_distinct_audit_rows(ctx, audit_artifacts, rlwe_pk):
         rc, proof, pw = orc.prove(row, 31 * i + 3, 37 * i + 5)
         assert rc == 0 and pl[i] == proof and wl[i] == pw, i
     assert all(ctx.verify_batch(open(audit_artifacts["vk"], "rb").read(), pl, wl))
+
+
+def test_audit_batch_refuses_bad_rows_in_place(ctx, audit_artifacts, rlwe_pk):
+    """The batch path of the matrix evaluation (run kernel + the integer "small rows" of the 1 088 quotient equations,
+    generate_audit.py:539-554) refuses, lane by lane: a quotient off by one, a noise value outside the range-check table, a noise
+    value inside the table that breaks its equation, a ciphertext byte changed -- and proves the 124 good rows around them."""
+    from spp import workload
+    B_ = 128
+    rows = bytearray(workload.audit_rows(ctx, rlwe_pk["a"], rlwe_pk["b"], B_, first=900))
+    n_in = 3360
+    R_ = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    def poke(i, idx, fn):
+        off = 32 * (n_in * i + idx)
+        v = fn(int.from_bytes(rows[off:off + 32], "big")) % R_
+        rows[off:off + 32] = v.to_bytes(32, "big")
+    poke(5, 2336 + 7, lambda v: v + 1)          # k1[7] + 1
+    poke(70, 160 + 3, lambda v: 300)            # r[3] = 300: not in [-128, 127]
+    poke(71, 160 + 3, lambda v: v + 1)          # r[3] + 1: in the table, equation broken
+    poke(127, 2 + 10 + 5, lambda v: v ^ 1)      # one bit of a packed ciphertext word
+    h = ctx.load_circuit(audit_artifacts["sppc"], audit_artifacts["pk"], 6)
+    try:
+        import ctypes
+        proofs = ctypes.create_string_buffer(388 * B_)
+        pws = ctypes.create_string_buffer(76 * B_)
+        status = (ctypes.c_int32 * B_)()
+        rc = h.L.spp_prove_batch(h.h, B_, bytes(rows), None, ctypes.cast(proofs, ctypes.c_void_p), ctypes.cast(pws, ctypes.c_void_p),
+                                 ctypes.cast(status, ctypes.c_void_p))
+        assert rc == -4
+        bad = {5, 70, 71, 127}
+        assert [i for i in range(B_) if status[i] != 0] == sorted(bad)
+        pl = [proofs.raw[388 * i:388 * (i + 1)] for i in range(B_) if i not in bad]
+        wl = [pws.raw[76 * i:76 * (i + 1)] for i in range(B_) if i not in bad]
+    finally:
+        h.close()
+    assert all(ctx.verify_batch(open(audit_artifacts["vk"], "rb").read(), pl, wl))
+    assert all(proofs.raw[388 * i:388 * (i + 1)] == b"\x00" * 388 for i in bad)
 
 
 def test_batched_verifier_matches_the_single_proof_verifiers(ctx, withdraw_handle, withdraw_artifacts, audit_artifacts, withdraw_kat, rlwe_pk):
