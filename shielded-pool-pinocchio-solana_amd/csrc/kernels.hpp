@@ -51,6 +51,9 @@ struct DevCircuit {
   const uint32_t* sm_rowptr;    // per small row: terms [rowptr[r], rowptr[r+1])
   const uint32_t* sm_slot;      // slot of a term
   const int32_t* sm_coef;       // its coefficient
+  const uint32_t* sm_rest_ptr;  // per small row: its few OTHER terms (any wire, any coefficient) [rest_ptr[r], rest_ptr[r+1]),
+  const uint32_t* sm_rest_wire; //   added with field arithmetic (the quotient k * q and the message bits of a quotient equation)
+  const uint32_t* sm_rest_coeff;//   index into coeffs
   const uint32_t* sm_row_out;   // matrix (0 = A, 1 = B, 2 = C) << 30 | constraint
   uint32_t sm_nrows;
   const uint8_t* row_small;     // per constraint: bit 0 A, bit 1 B, bit 2 C is a small row (nullptr: none)

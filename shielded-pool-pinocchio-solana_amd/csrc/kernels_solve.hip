@@ -800,8 +800,8 @@ __global__ void __launch_bounds__(256) k_small_extract(DevCircuit dc, const Fr* 
 }
 // small row r, proof p: sum of coefficient * small value as a 64-bit integer (|sum| < 2^31 * 2^15 * terms), stored as a field
 // element where k_spmv_check expects the row's value
-__global__ void __launch_bounds__(256) k_spmv_small_rows(DevCircuit dc, const int16_t* __restrict__ small, Fr* __restrict__ abc, uint32_t n,
-                                                         uint32_t P) {
+__global__ void __launch_bounds__(256) k_spmv_small_rows(DevCircuit dc, const int16_t* __restrict__ small, const Fr* __restrict__ W,
+                                                         Fr* __restrict__ abc, uint32_t n, uint32_t P) {
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= (uint64_t)dc.sm_nrows * P) return;
   const uint32_t p = (uint32_t)(g % P), r = (uint32_t)(g / P);
@@ -810,7 +810,9 @@ __global__ void __launch_bounds__(256) k_spmv_small_rows(DevCircuit dc, const in
   for (uint32_t t = b; t < e; t++) acc += (long long)dc.sm_coef[t] * (long long)small[(size_t)dc.sm_slot[t] * P + p];
   const uint32_t ro = dc.sm_row_out[r], mat = ro >> 30, k = ro & 0x3fffffffu;
   const Fr mag = Fr::from_u64((uint64_t)(acc < 0 ? -acc : acc));
-  abc[(size_t)mat * n * P + (size_t)k * P + p] = acc < 0 ? mag.neg() : mag;
+  Fr v = acc < 0 ? mag.neg() : mag;
+  for (uint32_t t = dc.sm_rest_ptr[r]; t < dc.sm_rest_ptr[r + 1]; t++) v = v + dc.coeffs[dc.sm_rest_coeff[t]] * W[(size_t)dc.sm_rest_wire[t] * P + p];
+  abc[(size_t)mat * n * P + (size_t)k * P + p] = v;
 }
 
 // lane -> (run r of constraints with one shared B row, proof p); lanes past the last run zero-fill the padding rows
@@ -893,7 +895,7 @@ void launch_spmv_check(hipStream_t st, DevCircuit dc, const Fr* W, Fr* abc, uint
   if (small && dc.sm_nrows) {
     const uint64_t l1 = (uint64_t)dc.sm_nslots * P, l2 = (uint64_t)dc.sm_nrows * P;
     hipLaunchKernelGGL(k_small_extract, dim3((uint32_t)((l1 + 255) / 256)), dim3(256), 0, st, dc, W, small, P, status);
-    hipLaunchKernelGGL(k_spmv_small_rows, dim3((uint32_t)((l2 + 255) / 256)), dim3(256), 0, st, dc, small, abc, n, P);
+    hipLaunchKernelGGL(k_spmv_small_rows, dim3((uint32_t)((l2 + 255) / 256)), dim3(256), 0, st, dc, small, W, abc, n, P);
   } else {
     dc.row_small = nullptr;
   }

@@ -481,7 +481,7 @@ static int coop_plan(spp_circuit* c) {
 // re-read the same 1 024 witness rows 1 088 times -- 73 GB of L2 misses per 2 048-proof batch in the general kernel (20 ms,
 // profiles/round2_audit_b2048_pmc_hbm.json); as integers over a 13 MB array they take well under a millisecond.
 // SPP_NO_SMALL_ROWS=1 (diagnostic): off.
-static constexpr uint32_t SMALL_ROW_MIN = 64;
+static constexpr uint32_t SMALL_ROW_MIN = 64, SMALL_ROW_REST = 32;
 static int small_rows_plan(spp_circuit* c) {
   const Circuit& circ = c->circ;
   c->dc.sm_nrows = 0;
@@ -526,7 +526,7 @@ static int small_rows_plan(spp_circuit* c) {
     }
   }
   if (wires.size() < 2) return 0;
-  std::vector<uint32_t> rowptr{0}, slots, row_out;
+  std::vector<uint32_t> rowptr{0}, slots, row_out, rest_ptr{0}, rest_wire, rest_coeff;
   std::vector<int32_t> coefs;
   std::vector<uint8_t> flags(std::max<uint32_t>(circ.n_constraints, 1), 0);
   const Sparse* mats[3] = {&circ.A, &circ.B, &circ.C};
@@ -535,19 +535,26 @@ static int small_rows_plan(spp_circuit* c) {
     for (uint32_t k = 0; k < circ.n_constraints; k++) {
       const uint32_t b = m.rowptr[k], e = m.rowptr[k + 1];
       if (e - b < SMALL_ROW_MIN || e - b > (1u << 20)) continue;
-      bool ok = true;
-      for (uint32_t t = b; t < e && ok; t++) {
+      // terms that qualify (small coefficient x byte-ranged wire) go to the integer sum, at most SMALL_ROW_REST others stay
+      // field arithmetic (a quotient equation has nine: k * q and the eight message bits times Delta * 2^i)
+      uint32_t n_small = 0;
+      for (uint32_t t = b; t < e; t++) {
         int64_t v;
-        ok = slot_of[m.terms[t].wire] >= 0 && small_of(m.terms[t].coeff, &v);
+        if (slot_of[m.terms[t].wire] >= 0 && small_of(m.terms[t].coeff, &v)) n_small++;
       }
-      if (!ok) continue;
+      if (n_small < SMALL_ROW_MIN || (e - b) - n_small > SMALL_ROW_REST) continue;
       for (uint32_t t = b; t < e; t++) {
         int64_t v = 0;
-        small_of(m.terms[t].coeff, &v);
-        slots.push_back((uint32_t)slot_of[m.terms[t].wire]);
-        coefs.push_back((int32_t)v);
+        if (slot_of[m.terms[t].wire] >= 0 && small_of(m.terms[t].coeff, &v)) {
+          slots.push_back((uint32_t)slot_of[m.terms[t].wire]);
+          coefs.push_back((int32_t)v);
+        } else {
+          rest_wire.push_back(m.terms[t].wire);
+          rest_coeff.push_back(m.terms[t].coeff);
+        }
       }
       rowptr.push_back((uint32_t)slots.size());
+      rest_ptr.push_back((uint32_t)rest_wire.size());
       row_out.push_back((mi << 30) | k);
       flags[k] |= (uint8_t)(1u << mi);
     }
@@ -555,13 +562,16 @@ static int small_rows_plan(spp_circuit* c) {
   if (row_out.empty()) return 0;
   // a run of constraints shares ONE B evaluation (its first row's): the flag of the first row decides for the run, and the rows of
   // a run have identical B rows, so they qualify together
-  uint32_t *d_w, *d_rp, *d_sl, *d_ro;
+  uint32_t *d_w, *d_rp, *d_sl, *d_ro, *d_xp, *d_xw, *d_xc;
   int32_t *d_lo, *d_co;
   uint8_t* d_fl;
   int e;
+  if (rest_wire.empty()) { rest_wire.push_back(0); rest_coeff.push_back(0); }   // never read: keeps the uploads non-empty
   if ((e = own_upload(c, &d_w, wires)) || (e = own_upload(c, &d_lo, lo)) || (e = own_upload(c, &d_rp, rowptr)) || (e = own_upload(c, &d_sl, slots)) ||
-      (e = own_upload(c, &d_co, coefs)) || (e = own_upload(c, &d_ro, row_out)) || (e = own_upload(c, &d_fl, flags)))
+      (e = own_upload(c, &d_co, coefs)) || (e = own_upload(c, &d_ro, row_out)) || (e = own_upload(c, &d_fl, flags)) ||
+      (e = own_upload(c, &d_xp, rest_ptr)) || (e = own_upload(c, &d_xw, rest_wire)) || (e = own_upload(c, &d_xc, rest_coeff)))
     return e;
+  c->dc.sm_rest_ptr = d_xp; c->dc.sm_rest_wire = d_xw; c->dc.sm_rest_coeff = d_xc;
   c->dc.sm_wires = d_w; c->dc.sm_lo = d_lo; c->dc.sm_nslots = (uint32_t)wires.size();
   c->dc.sm_rowptr = d_rp; c->dc.sm_slot = d_sl; c->dc.sm_coef = d_co; c->dc.sm_row_out = d_ro; c->dc.sm_nrows = (uint32_t)row_out.size();
   c->dc.row_small = d_fl;
