@@ -576,7 +576,7 @@ def main():
         windows = dict(zip(INFO_ORDER, h.msm_windows()))
         # algorithmic bytes of one k_msm_flat launch over a batch (64 B per base once + one 32 B scalar per (base, proof))
         alg = {s: (128 if s.startswith("B2") else 64) * sizes[s] + 32 * sizes[s] * B for s in SETS}
-        g1 = SETS[:6]
+        g1 = ["A", "B1", "K", "Z"]     # the four k_msm_flat<Fq> launches of a step (CB / CS: small row-per-window tables, k_msm_rows)
         ser = {s: probe["kern"][i] / probe["n"] for i, s in enumerate(SETS)}
         pip = {s: acc["kern"][i] / acc["n"] for i, s in enumerate(SETS)}
         ser_g1_ms = sum(ser[s] for s in g1)
@@ -589,9 +589,9 @@ def main():
             # change cannot inherit an older kernel's traffic
             if pmc.get("circuit") == circuit and pmc.get("batch") == B and pmc.get("n_distinct_witnesses") == B \
                     and pmc.get("libspp_sha256") == libspp_sha256():
-                traffic = pmc["k_msm_fixed_g1_hbm_bytes_per_launch"]
+                traffic = pmc["k_msm_flat_g1_hbm_bytes_per_launch"]
                 traffic_src = pmc.get("source")
-                valu_util = pmc.get("k_msm_fixed_g1_valu_issue_util_serialised")
+                valu_util = pmc.get("k_msm_flat_g1_valu_issue_util_serialised")
         except Exception:
             pass
         out = {
@@ -610,12 +610,12 @@ def main():
                 ["solve+commit", "matrix_eval", "ntt_qap", "msm_g1", "msm_g2", "assemble", "total"], probe["stage"])},
             "roofline": {"bound": "hbm", "kernel": "k_msm_flat<Fq>", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
-                         "alg_bytes_per_launch": int(alg_g1 / 6), "avg_launch_ms": round(ser_g1_ms / 6, 4), "launches_per_step": 6,
+                         "alg_bytes_per_launch": int(alg_g1 / 4), "avg_launch_ms": round(ser_g1_ms / 4, 4), "launches_per_step": 4,
                          "launch_ms_serialised": {s: round(ser[s], 3) for s in SETS},
                          "launch_ms_in_pipelined_timed_region": {s: round(pip[s], 3) for s in SETS},
                          "launch_GBps_serialised": {s: round(alg[s] / (ser[s] * 1e-3) / 1e9, 2) if ser[s] > 0 else None for s in SETS},
                          "timing": "dispatch timestamps (hipExtLaunchKernelGGL events); `achieved` uses the serialised probe (3 steps on one stream after "
-                                   "the timed region): 6 launches x avg_launch_ms <= ms_per_step; in the pipelined region the same dispatches share the chip",
+                                   "the timed region): 4 launches x avg_launch_ms <= ms_per_step; in the pipelined region the same dispatches share the chip",
                          "valu_issue_util_pmc": valu_util,
                          "msm_table_rows": dict(zip(INFO_ORDER, h.msm_table_rows())),
                          "note": "integer-VALU bound (about 2.3K instructions, 1.5K of them v_mad_u64_u32, per mixed addition; 16-17 additions per "

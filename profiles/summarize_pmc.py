@@ -41,12 +41,28 @@ def main():
                       "hbm_bytes_per_launch_corrected": int((2 * fe["avg_kb"] + wr["avg_kb"]) * 1024)}
     doc = {"units": "KB per dispatch as reported; corrected HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024", "kernels": kernels}
     json.dump(doc, open(out, "w"), indent=1)
-    if len(sys.argv) >= 7 and os.environ.get("SPP_WRITE_LATEST"):   # pmc_hbm_latest.json carries more keys: profiles/README of the round
-        g1 = [v for k, v in kernels.items() if "k_msm_fixed<spp::Fp<spp::FqParams>" in k.replace(" ", "")
-              or ("k_msm_fixed" in k and "FqParams" in k)]
+    if len(sys.argv) >= 7 and os.environ.get("SPP_WRITE_LATEST"):   # pmc_hbm_latest.json: what bench.py reads for roofline.traffic
+        import hashlib
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        lib = os.path.join(root, "shielded-pool-pinocchio-solana_amd", "libspp.so")
+        pick = lambda kern, field: [v for k, v in kernels.items() if kern in k and field in k]
+        g1, g2 = pick("k_msm_flat", "FqParams"), pick("k_msm_flat", "Fq2")
         if g1:
-            latest = {"circuit": sys.argv[4], "batch": int(sys.argv[5]), "window_bits": int(sys.argv[6]),
-                      "k_msm_fixed_g1_hbm_bytes_per_launch": g1[0]["hbm_bytes_per_launch_corrected"], "source": os.path.basename(out)}
+            latest = {"circuit": sys.argv[4], "batch": int(sys.argv[5]), "n_distinct_witnesses": int(sys.argv[5]), "window_bits": int(sys.argv[6]),
+                      "libspp_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(),
+                      "k_msm_flat_g1_hbm_bytes_per_launch": g1[0]["hbm_bytes_per_launch_corrected"],
+                      "k_msm_flat_g2_hbm_bytes_per_launch": g2[0]["hbm_bytes_per_launch_corrected"] if g2 else None,
+                      "source": "profiles/%s (separate FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes)" % os.path.basename(out)}
+            valu = os.environ.get("SPP_VALU_JSON")
+            if valu and os.path.exists(valu):
+                vd = json.load(open(valu))
+                for k, v in vd.items():
+                    if "k_msm_flat" in k and "FqParams" in k:
+                        latest["k_msm_flat_g1_valu_issue_util_serialised"] = v.get("valu_issue_util")
+                        latest["k_msm_flat_g1_resident_waves_per_simd"] = v.get("mean_resident_waves_per_simd")
+                    if "k_msm_flat" in k and "Fq2" in k:
+                        latest["k_msm_flat_g2_valu_issue_util_serialised"] = v.get("valu_issue_util")
+                latest["source"] += " and profiles/%s (SQ counters, SPP_SERIAL=1)" % os.path.basename(valu)
             json.dump(latest, open(os.path.join(os.path.dirname(out) or ".", "pmc_hbm_latest.json"), "w"), indent=1)
             print(latest)
 

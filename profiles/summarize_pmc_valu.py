@@ -40,7 +40,7 @@ def main():
         doc[name] = row
     json.dump(doc, open(out, "w"), indent=1)
     for k, v in doc.items():
-        if "k_msm_fixed" in k or "k_ntt" in k:
+        if "k_msm_flat" in k or "k_ntt" in k or "k_spmv" in k:
             print(k[:60], {x: v.get(x) for x in ("kernel_cycles", "valu_issue_util", "cycles_per_valu_wave_instruction", "mean_resident_waves_per_simd")})
 
 
