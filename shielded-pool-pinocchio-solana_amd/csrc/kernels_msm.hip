@@ -311,21 +311,58 @@ __global__ void __launch_bounds__(256) k_msm_flat(const Affine<F>* __restrict__ 
   const int16_t* __restrict__ dg = dig + ((size_t)rho * N) * Pp + p;
   MsmAcc<F> acc;
   acc.init();
-  for (uint32_t i0 = sl; i0 < N; i0 += 4 * Sg) {
-    uint64_t pack = 0;
-    SPP_UNROLL for (uint32_t k = 0; k < 4; k++) {
-      const uint32_t i = i0 + k * Sg;
-      const uint32_t d = i < N ? (uint32_t)(uint16_t)dg[(size_t)i * Pp] : 0u;
-      pack |= (uint64_t)d << (16 * k);
-    }
-    if (pack == 0) continue;
+  if constexpr (sizeof(F) > sizeof(Fq)) {
+    // G2: one wave per SIMD (512 registers), nothing else to run while a gather is in flight -- the counters of the first
+    // version showed 59 % VALU issue.  One-deep software pipeline: the entry of the next non-zero digit is requested BEFORE the
+    // pending addition is computed.  A last pass over the loop body (flush) retires the pending addition, so that the ~40 KB
+    // of a G2 mixed addition are instantiated once.
+    int d_next = 0;
+    Affine<F> e_next;
+    for (uint32_t i0 = sl;; i0 += 4 * Sg) {
+      const bool last = i0 >= N;
+      uint64_t pack = 0;
+      if (!last) {
+        SPP_UNROLL for (uint32_t k = 0; k < 4; k++) {
+          const uint32_t i = i0 + k * Sg;
+          const uint32_t d = i < N ? (uint32_t)(uint16_t)dg[(size_t)i * Pp] : 0u;
+          pack |= (uint64_t)d << (16 * k);
+        }
+      }
 #pragma unroll 1
-    for (uint32_t k = 0; k < 4; k++) {
-      const int d = (int)(int16_t)(uint16_t)(pack >> (16 * k));
-      if (d != 0) {
+      for (uint32_t k = 0; k < 4; k++) {
+        const int d = (int)(int16_t)(uint16_t)(pack >> (16 * k));
+        const bool flush = last && k == 0;
+        if (d != 0 || flush) {
+          Affine<F> e;
+          if (d != 0) {
+            const uint32_t i = i0 + k * Sg;
+            const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+            e = table[((size_t)(i >> 6) * E + (mag - 1)) * 64 + (i & 63)];
+          }
+          if (d_next != 0) acc.madd(e_next, d_next < 0);
+          d_next = d;
+          if (d != 0) e_next = e;
+        }
+      }
+      if (last) break;
+    }
+  } else {
+    for (uint32_t i0 = sl; i0 < N; i0 += 4 * Sg) {
+      uint64_t pack = 0;
+      SPP_UNROLL for (uint32_t k = 0; k < 4; k++) {
         const uint32_t i = i0 + k * Sg;
-        const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-        acc.madd(table[((size_t)(i >> 6) * E + (mag - 1)) * 64 + (i & 63)], d < 0);
+        const uint32_t d = i < N ? (uint32_t)(uint16_t)dg[(size_t)i * Pp] : 0u;
+        pack |= (uint64_t)d << (16 * k);
+      }
+      if (pack == 0) continue;
+#pragma unroll 1
+      for (uint32_t k = 0; k < 4; k++) {
+        const int d = (int)(int16_t)(uint16_t)(pack >> (16 * k));
+        if (d != 0) {
+          const uint32_t i = i0 + k * Sg;
+          const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+          acc.madd(table[((size_t)(i >> 6) * E + (mag - 1)) * 64 + (i & 63)], d < 0);
+        }
       }
     }
   }
