@@ -424,4 +424,5 @@ def hash_to_fr(msg, dst, count=1):
 
 
 DST_COMMITMENT = b'bsb22-commitment'   # string present in audit_circuit/target/audit_verifier.so
+DST_MASK = b'spp-commit-mask1'         # the commitment's hiding mask (OP_MASK): its own domain
 DST_FOLD = b'G16-BSB22'

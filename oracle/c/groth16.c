@@ -431,7 +431,7 @@ static int solve(const circuit_t* c, fe* w, challenge_fn chal, void* chal_ctx, c
       case OP_MASK: {   /* fr.Hash(r || s): the hiding mask gnark's api.Commit adds (hints.Randomize) */
         uint32_t out = pr[pc + 1];
         pc += 2;
-        orc_hash_to_fr(rs64, 64, "bsb22-commitment", &w[out], 1);
+        orc_hash_to_fr(rs64, 64, "spp-commit-mask1", &w[out], 1);   /* a tag of its own: not the challenge's domain */
         break;
       }
       default:

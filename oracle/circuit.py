@@ -126,9 +126,10 @@ def _poseidon2_native(state, out, w):
 
 
 def mask_value(r, s):
-    """the commitment's random mask (OP_MASK): fr.Hash(r || s, "bsb22-commitment") of the proof's blinding factors"""
-    from .bn254 import hash_to_fr, DST_COMMITMENT
-    return hash_to_fr((r % R).to_bytes(32, "big") + (s % R).to_bytes(32, "big"), DST_COMMITMENT)[0]
+    """the commitment's random mask (OP_MASK): fr.Hash(r || s, "spp-commit-mask1") of the proof's blinding factors -- a tag of its own,
+    so that the mask and the commitment challenge (tag "bsb22-commitment") never come out of one random-oracle domain"""
+    from .bn254 import hash_to_fr, DST_MASK
+    return hash_to_fr((r % R).to_bytes(32, "big") + (s % R).to_bytes(32, "big"), DST_MASK)[0]
 
 
 def solve(circ, inputs, challenge_fn, rs=(0, 0)):

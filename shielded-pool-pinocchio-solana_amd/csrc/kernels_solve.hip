@@ -350,7 +350,7 @@ __device__ __forceinline__ void solve_range(const DevCircuit& dc, Fr* __restrict
         dev_poseidon2(s, dc.p2_rc, dc.p2_mu, W, out0, P, p);
         break;
       }
-      case OP_MASK: {        // the commitment's random mask: fr.Hash(r || s) of the proof's blinding factors (rows n_wires, n_wires + 1)
+      case OP_MASK: {        // the commitment's random mask: fr.Hash(r || s, "spp-commit-mask1") of the proof's blinding factors (rows n_wires, n_wires + 1)
         const uint32_t out = pr[pc + 1];
         pc += 2;
         uint32_t m[16], cw[8];
@@ -358,7 +358,7 @@ __device__ __forceinline__ void solve_range(const DevCircuit& dc, Fr* __restrict
         SPP_UNROLL for (int i = 0; i < 8; i++) m[i] = cw[7 - i];
         W[(size_t)(dc.n_wires + 1) * P + p].to_canonical(cw);
         SPP_UNROLL for (int i = 0; i < 8; i++) m[8 + i] = cw[7 - i];
-        W[(size_t)out * P + p] = bsb22_challenge(m);
+        W[(size_t)out * P + p] = commitment_mask(m);
         break;
       }
       case OP_GRUMPKIN: {

@@ -130,9 +130,26 @@ SPP_HD Fr fr_from_wide48(const uint32_t w[12]) {
   return l + hm;
 }
 
-// fr.Hash(commitment, "bsb22-commitment"): expand_message_xmd(SHA-256) of the 64 commitment bytes (16 big-endian
-// words, x then y), 48 output bytes -> Fr.  Blocks are laid out by hand (message 64 B, DST 16 B).
-SPP_HD Fr bsb22_challenge(const uint32_t m[16]) {
+// fr.Hash(msg, DST) for a 64-byte message and a 16-byte domain-separation tag: expand_message_xmd(SHA-256), 48 output bytes -> Fr.
+// Blocks are laid out by hand (message 16 big-endian words, DST 16 B).  Two tags are in use, one per protocol value, so that the
+// two never come out of the same random-oracle domain:
+//   DstCommitment "bsb22-commitment"  the commitment challenge fr.Hash(Cm.x || Cm.y) (gnark's tag; the string is in the reference's
+//                                     audit_circuit/target/audit_verifier.so)
+//   DstMask       "spp-commit-mask1"  the commitment's hiding mask, derived from the proof's blinding factors r || s (OP_MASK)
+struct DstCommitment { static SPP_HD constexpr uint32_t b(int i) { constexpr char d[17] = "bsb22-commitment"; return (uint32_t)(uint8_t)d[i]; } };
+struct DstMask { static SPP_HD constexpr uint32_t b(int i) { constexpr char d[17] = "spp-commit-mask1"; return (uint32_t)(uint8_t)d[i]; } };
+template <class D>
+SPP_HD Fr hash64_to_fr(const uint32_t m[16]) {
+  constexpr uint32_t w0 = 0x00300000u | D::b(0);
+  constexpr uint32_t w1 = (D::b(1) << 24) | (D::b(2) << 16) | (D::b(3) << 8) | D::b(4);
+  constexpr uint32_t w2 = (D::b(5) << 24) | (D::b(6) << 16) | (D::b(7) << 8) | D::b(8);
+  constexpr uint32_t w3 = (D::b(9) << 24) | (D::b(10) << 16) | (D::b(11) << 8) | D::b(12);
+  constexpr uint32_t w4 = (D::b(13) << 24) | (D::b(14) << 16) | (D::b(15) << 8) | 0x10u;
+  constexpr uint32_t x0 = (D::b(0) << 16) | (D::b(1) << 8) | D::b(2);            // low 24 bits of the word that starts with the block counter
+  constexpr uint32_t x1 = (D::b(3) << 24) | (D::b(4) << 16) | (D::b(5) << 8) | D::b(6);
+  constexpr uint32_t x2 = (D::b(7) << 24) | (D::b(8) << 16) | (D::b(9) << 8) | D::b(10);
+  constexpr uint32_t x3 = (D::b(11) << 24) | (D::b(12) << 16) | (D::b(13) << 8) | D::b(14);
+  constexpr uint32_t x4 = (D::b(15) << 24) | 0x00108000u;
   uint32_t blk[16];
   // b0 = H(Z_pad || msg || I2OSP(48,2) || 0 || DST || len(DST))
   Sha256 s0;
@@ -140,7 +157,7 @@ SPP_HD Fr bsb22_challenge(const uint32_t m[16]) {
   for (int i = 0; i < 16; i++) blk[i] = 0;
   s0.compress(blk);
   s0.compress(m);
-  blk[0] = 0x00300062u; blk[1] = 0x73623232u; blk[2] = 0x2d636f6du; blk[3] = 0x6d69746du; blk[4] = 0x656e7410u; blk[5] = 0x80000000u;
+  blk[0] = w0; blk[1] = w1; blk[2] = w2; blk[3] = w3; blk[4] = w4; blk[5] = 0x80000000u;
   for (int i = 6; i < 15; i++) blk[i] = 0;
   blk[15] = 0x4a0u;
   s0.compress(blk);
@@ -148,19 +165,21 @@ SPP_HD Fr bsb22_challenge(const uint32_t m[16]) {
   Sha256 s1;
   s1.init();
   for (int i = 0; i < 8; i++) blk[i] = s0.h[i];
-  blk[8] = 0x01627362u; blk[9] = 0x32322d63u; blk[10] = 0x6f6d6d69u; blk[11] = 0x746d656eu; blk[12] = 0x74108000u;
+  blk[8] = 0x01000000u | x0; blk[9] = x1; blk[10] = x2; blk[11] = x3; blk[12] = x4;
   blk[13] = 0; blk[14] = 0; blk[15] = 0x190u;
   s1.compress(blk);
   // b2 = H((b0 ^ b1) || 2 || DST')
   Sha256 s2;
   s2.init();
   for (int i = 0; i < 8; i++) blk[i] = s0.h[i] ^ s1.h[i];
-  blk[8] = 0x02627362u;
+  blk[8] = 0x02000000u | x0;
   s2.compress(blk);
   uint32_t wide[12];
   for (int i = 0; i < 8; i++) wide[i] = s1.h[i];
   for (int i = 0; i < 4; i++) wide[8 + i] = s2.h[i];
   return fr_from_wide48(wide);
 }
+SPP_HD Fr bsb22_challenge(const uint32_t m[16]) { return hash64_to_fr<DstCommitment>(m); }
+SPP_HD Fr commitment_mask(const uint32_t m[16]) { return hash64_to_fr<DstMask>(m); }
 
 }  // namespace spp

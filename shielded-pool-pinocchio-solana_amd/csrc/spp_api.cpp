@@ -735,10 +735,17 @@ extern "C" int spp_init(int device, spp_ctx** out) {
   HIP_TRY(hipSetDevice(device));
   spp_ctx* ctx = new spp_ctx();
   ctx->device = device;
+  ctx->stream = nullptr;
+  for (int k = 0; k < SPP_NWS; k++) ctx->pstream[k] = nullptr;
+  struct Guard {   // a failure below must not leak the context and the streams created so far
+    spp_ctx* ctx;
+    ~Guard() { if (ctx) spp_free_ctx(ctx); }
+  } guard{ctx};
   HIP_TRY(hipStreamCreate(&ctx->stream));
   HIP_TRY(hipStreamCreate(&ctx->pstream[0]));
   for (int k = 1; k < SPP_NWS; k++)
     if (int e = pick_concurrent_stream(ctx->pstream[0], &ctx->pstream[k])) return e;
+  guard.ctx = nullptr;
   *out = ctx;
   return SPP_OK;
 }
@@ -776,8 +783,9 @@ static int pick_concurrent_stream(hipStream_t ref, hipStream_t* out) {
 extern "C" void spp_free_ctx(spp_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
-  hipStreamDestroy(ctx->stream);
-  for (int k = 0; k < SPP_NWS; k++) hipStreamDestroy(ctx->pstream[k]);
+  if (ctx->stream) hipStreamDestroy(ctx->stream);
+  for (int k = 0; k < SPP_NWS; k++)
+    if (ctx->pstream[k]) hipStreamDestroy(ctx->pstream[k]);
   for (void* p : ctx->owned) hipFree(p);
   if (ctx->audit_scratch) hipFree(ctx->audit_scratch);
   delete ctx;
@@ -1790,9 +1798,9 @@ extern "C" int spp_prove_withdraw(spp_circuit* c, const spp_withdraw_inputs* in,
 
 extern "C" int spp_debug_witness(spp_circuit* c, uint8_t* out, size_t n_wires) {
   if (!c || !out) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
+  std::lock_guard<std::mutex> lk(c->ctx->mu);
   Workspace& w = c->ws[c->last_ws];
   if (w.cap == 0) return fail(SPP_ERR_BAD_INPUT, "no batch has been proved yet");
-  std::lock_guard<std::mutex> lk(c->ctx->mu);
   HIP_TRY(hipSetDevice(c->ctx->device));
   HIP_TRY(hipStreamSynchronize(w.st));
   size_t P = w.last_P;   // column 0 of W at the stride of the last batch

@@ -108,9 +108,13 @@ extern "C" int spp_verify_batch(spp_ctx* ctx, const uint8_t* vk, size_t vk_len, 
   UP(dproofs, proofs, count * (size_t)SPP_PROOF_LEN);
   UP(dpws, pws, count * pw_len);
   HIP_TRY(dok.alloc(count * sizeof(int32_t)));
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
+  struct Ev {   // destroyed on every return path
+    hipEvent_t e = nullptr;
+    ~Ev() { if (e) hipEventDestroy(e); }
+  } ev0, ev1;
+  HIP_TRY(hipEventCreate(&ev0.e));
+  HIP_TRY(hipEventCreate(&ev1.e));
+  hipEvent_t e0 = ev0.e, e1 = ev1.e;
   hipEventRecord(e0, st);
   launch_verify(st, dvk.as<VerifyKeyDev>(), dproofs.as<uint8_t>(), dpws.as<uint8_t>(), (uint32_t)pw_len, (uint32_t)count, dok.as<int32_t>());
   hipEventRecord(e1, st);
@@ -118,8 +122,6 @@ extern "C" int spp_verify_batch(spp_ctx* ctx, const uint8_t* vk, size_t vk_len, 
   HIP_TRY(hipGetLastError());
   float ms = 0;
   hipEventElapsedTime(&ms, e0, e1);
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
   if (kernel_ms) *kernel_ms = ms;
   HIP_TRY(hipMemcpy(ok, dok.p, count * sizeof(int32_t), hipMemcpyDeviceToHost));
   return SPP_OK;

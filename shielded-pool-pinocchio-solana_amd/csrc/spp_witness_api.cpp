@@ -287,13 +287,14 @@ extern "C" uint64_t spp_merkle_tree_size(const spp_merkle_tree* t) { return t ? 
 // insert(commitment) (merkle.ts:158-163) for `count` leaves at once; *first_index receives the index of the first one
 extern "C" int spp_merkle_tree_insert(spp_merkle_tree* t, size_t count, const uint8_t* leaves, uint64_t* first_index) {
   if (!t || (count && !leaves)) return fail(SPP_ERR_BAD_INPUT, "NULL argument");
-  if (first_index) *first_index = t->n_leaves;
-  if (count == 0) return SPP_OK;
-  if (count > ((uint64_t)1 << t->depth) - t->n_leaves) return fail(SPP_ERR_BAD_INPUT, "tree is full");
   for (size_t i = 0; i < count; i++)
     if (!be_is_canonical<FrParams>(leaves + 32 * i)) return fail(SPP_ERR_BAD_INPUT, "leaf %zu is not a canonical field element", i);
   spp_ctx* ctx = t->ctx;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::mutex> lk(ctx->mu);   // the size, the first index handed out and the "full" check are read under the lock:
+                                             // two inserting threads must not get the same index
+  if (first_index) *first_index = t->n_leaves;
+  if (count == 0) return SPP_OK;
+  if (count > ((uint64_t)1 << t->depth) - t->n_leaves) return fail(SPP_ERR_BAD_INPUT, "tree is full");
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   if (int e = mt_reserve(t, t->n_leaves + count)) return e;

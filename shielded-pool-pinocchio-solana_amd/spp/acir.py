@@ -116,6 +116,7 @@ def _opcode(r):
             return ("MultiScalarMul", points, scalars, predicate, (r.u32(), r.u32(), r.u32()))
         raise AcirFormatError("BlackBoxFuncCall %d at offset %d is not used by the reference's circuits" % (bb, at))
     if tag == 4:
+        r.brillig_id_offsets = getattr(r, "brillig_id_offsets", []) + [r.o]
         fid = r.u32()
 
         def binput():
@@ -151,6 +152,7 @@ class Circuit:
         self.public_parameters = r.vec(r.u32)
         self.return_values = r.vec(r.u32)
         self.end_of_parameters = r.o      # assert messages and the Brillig functions follow (not decoded)
+        self.brillig_id_offsets = list(getattr(r, "brillig_id_offsets", []))   # byte offsets of the BrilligCall function ids
 
     def histogram(self):
         h = {}
@@ -169,6 +171,32 @@ class Program:
         if n != 1:
             raise AcirFormatError("%d ACIR functions (the reference's programs have one)" % n)
         self.main = Circuit(r)
+        # what follows the main function: its assert messages and the Brillig ("unconstrained") functions.  Their bytecode is never
+        # interpreted here; it is IDENTIFIED: see brillig_kind
+        import hashlib
+        self.unconstrained_sha256 = hashlib.sha256(self.raw[self.main.end_of_parameters:]).hexdigest()
+
+    def brillig_kind(self, index, fid, inputs, outputs):
+        """What the Brillig function `fid` computes, for BOTH consumers (execute and to_blob): 'divmod' (a, b) -> (a // b, a % b),
+        'inverse' x -> 1/x (0 for 0), 'radix' (x, n, radix) -> n little-endian digits.  The functions are identified by CONTENT: a
+        program is accepted only when its unconstrained section is byte-identical to that of the reference's compiled withdraw circuit
+        (noir_circuit/target/shielded_pool_verifier.json = tests/golden/reference_withdraw_acir.json, noir 1.0.0-beta.18), whose three
+        helpers are known; every call site must also have the shape its helper takes.  Anything else -- another compiler version's
+        helper bodies, a helper this module has no host implementation of, a call site whose shape does not fit -- is an
+        AcirFormatError here rather than a silently wrong hint and an 'inputs do not satisfy the circuit' later."""
+        if self.unconstrained_sha256 != REFERENCE_UNCONSTRAINED_SHA256:
+            raise AcirFormatError("opcode %d: the program's unconstrained (Brillig) functions are not the reference's (sha256 %s...): Brillig "
+                                  "bytecode is not interpreted, only programs carrying the helper functions of noir_circuit/target/"
+                                  "shielded_pool_verifier.json are supported" % (index, self.unconstrained_sha256[:16]))
+        kind = _REFERENCE_BRILLIG.get(fid)
+        if kind is None:
+            raise AcirFormatError("opcode %d: Brillig function %d has no host implementation" % (index, fid))
+        shape = (len(inputs), [o[0] for o in outputs], all(i[0] == "single" for i in inputs))
+        want = {"divmod": (2, ["simple", "simple"], True), "inverse": (1, ["simple"], True), "radix": (3, ["array"], True)}[kind]
+        if shape != want:
+            raise AcirFormatError("opcode %d: call of Brillig function %d (%s) with %d inputs and outputs %s does not have that helper's shape"
+                                  % (index, fid, kind, shape[0], shape[1]))
+        return kind
 
     def parameter_witnesses(self):
         """[(name, [witness indices])] in ABI order: parameters occupy consecutive witnesses from 0 (nargo's ABI encoding)."""
@@ -276,29 +304,36 @@ def _gk_mul(pt, k):
     return acc
 
 
+# sha256 of everything that follows the main function's parameters in the reference's compiled program (assert messages + the three
+# Brillig functions) and what those functions compute (ids as the program numbers them)
+REFERENCE_UNCONSTRAINED_SHA256 = "ebff9086f0484343725d1dc91d3cc5b1f88edd0018d64bcc4a38c136536d95ef"
+_REFERENCE_BRILLIG = {0: "divmod", 1: "inverse", 2: "radix"}
+
+
 class UnsatisfiedConstraint(ValueError):
     def __init__(self, index, what):
         super().__init__("ACIR opcode %d: %s" % (index, what))
         self.opcode_index = index
 
 
-def _brillig(fid, args, n_out):
-    """The three unconstrained helper functions of the reference's withdraw circuit, by their semantics (the constraints
-    that follow each call pin them): 0 = (a, b) -> (a // b, a % b) [field -> 128-bit limbs], 1 = x -> 1/x (0 -> 0) [is-zero
-    and != gadgets], 2 = (x, n, radix) -> n little-endian digits [index -> 16 path bits].  Brillig bytecode is not interpreted."""
-    if fid == 0:
+def _brillig(kind, args, n_out):
+    """Host implementations of the reference's unconstrained helpers, by kind (Program.brillig_kind): the constraints that follow
+    each call pin the results.  Brillig bytecode is not interpreted."""
+    if kind == "divmod":                      # field -> 128-bit limbs
         a, b = args[0], args[1]
+        if b == 0:
+            raise AcirFormatError("Brillig divmod by zero")
         return [a // b, a % b]
-    if fid == 1:
+    if kind == "inverse":                     # is-zero and != gadgets
         return [pow(args[0], -1, R) if args[0] % R else 0]
-    if fid == 2:
-        x, radix = args[0], args[2]          # (value, number of limbs, radix)
+    if kind == "radix":                       # (value, number of limbs, radix): index -> 16 path bits
+        x, radix = args[0], args[2]
         out = []
         for _ in range(n_out):
             out.append(x % radix)
             x //= radix
         return out
-    raise AcirFormatError("Brillig function %d has no host implementation" % fid)
+    raise AcirFormatError("Brillig helper %r has no host implementation" % (kind,))
 
 
 def execute(program, input_row):
@@ -377,6 +412,7 @@ def execute(program, input_row):
         elif kind == "BrilligCall":
             _, fid, inputs, outputs, predicate = op
             flat_out = [x for o in outputs for x in ([o[1]] if o[0] == "simple" else o[1])]
+            program.brillig_kind(idx, fid, inputs, outputs)   # identify the helper even when the predicate is off
             if predicate is not None and value(predicate) == 0:
                 for x in flat_out:
                     w[x] = 0
@@ -389,7 +425,7 @@ def execute(program, input_row):
                     args.extend(value(x) for x in i[1])
                 else:
                     raise AcirFormatError("opcode %d: Brillig memory inputs are not supported" % idx)
-            for x, v in zip(flat_out, _brillig(fid, args, len(flat_out))):
+            for x, v in zip(flat_out, _brillig(program.brillig_kind(idx, fid, inputs, outputs), args, len(flat_out))):
                 w[x] = v % R
     return w
 
@@ -410,8 +446,9 @@ def _expr_bytes(e):
 
 
 def to_blob(program):
-    """The decoded opcode list in the flat layout csrc/circuit_acir.cpp reads (see its header).  Brillig calls are classified by
-    their call shape -- the functions themselves are unconstrained helpers whose outputs the following opcodes constrain:
+    """The decoded opcode list in the flat layout csrc/circuit_acir.cpp reads (see its header).  Brillig calls are identified by
+    Program.brillig_kind (content of the unconstrained section + call shape; the same classifier execute() uses) -- the functions
+    themselves are unconstrained helpers whose outputs the following opcodes constrain:
       (expr, constant power of two) -> (q, r)            quotient / remainder    (field -> 128-bit limbs)
       (expr) -> (x)                                       inverse, 0 for 0        (is-zero / != gadgets)
       (expr, constant n, constant 2) -> [n witnesses]     little-endian bits      (index -> path bits)
@@ -445,16 +482,17 @@ def to_blob(program):
                 raise AcirFormatError("opcode %d: predicated / array-input Brillig calls are not supported" % i)
             exprs = [e for _, e in inputs]
             const = lambda e: not e.mul_terms and not e.linear
-            shape = (len(exprs), [o[0] for o in outputs])
-            if shape == (2, ["simple", "simple"]) and const(exprs[1]) and exprs[1].constant and exprs[1].constant & (exprs[1].constant - 1) == 0:
+            kind = program.brillig_kind(i, fid, inputs, outputs)     # the same identification execute() uses
+            if kind == "divmod" and const(exprs[1]) and exprs[1].constant and exprs[1].constant & (exprs[1].constant - 1) == 0:
                 ops.append(struct.pack("<I", 3) + _expr_bytes(exprs[0]) + struct.pack("<III", exprs[1].constant.bit_length() - 1, outputs[0][1], outputs[1][1]))
-            elif shape == (1, ["simple"]):
+            elif kind == "inverse":
                 ops.append(struct.pack("<I", 4) + _expr_bytes(exprs[0]) + struct.pack("<I", outputs[0][1]))
-            elif shape == (3, ["array"]) and const(exprs[1]) and const(exprs[2]) and exprs[2].constant == 2 and exprs[1].constant == len(outputs[0][1]):
+            elif kind == "radix" and const(exprs[1]) and const(exprs[2]) and exprs[2].constant == 2 and exprs[1].constant == len(outputs[0][1]):
                 outs = outputs[0][1]
                 ops.append(struct.pack("<I", 5) + _expr_bytes(exprs[0]) + struct.pack("<I%dI" % len(outs), len(outs), *outs))
             else:
-                raise AcirFormatError("opcode %d: Brillig call %d has an unrecognised shape" % (i, fid))
+                raise AcirFormatError("opcode %d: Brillig %s call with arguments the lowering does not cover (divisor not a constant power "
+                                      "of two / radix not 2)" % (i, kind))
         else:
             raise AcirFormatError("opcode %d: %s is not supported" % (i, k))
     return struct.pack("<IIII", 0x31524341, len(pub), len(sec), len(ops)) + b"".join(ops)

@@ -82,9 +82,23 @@ class ShieldedPoolMerkleTree:
         self.h = h
 
     def close(self):
-        if self.h:
+        if getattr(self, "h", None):
             self.ctx.L.spp_merkle_tree_free(self.h)
             self.h = None
+
+    # the levels live in HBM: release them when the object goes away (context manager or garbage collection), not only on close()
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # interpreter shutdown: the library may already be gone
+            pass
 
     def __len__(self):
         return int(self.ctx.L.spp_merkle_tree_size(self.h))

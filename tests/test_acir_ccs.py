@@ -99,6 +99,58 @@ def test_reference_acir_and_repository_r1cs_accept_the_same_statements(program, 
             acir.execute(program, bad)
 
 
+def _patched_program(doc, patch):
+    """the reference program with `patch(raw bytearray, Program)` applied to its decoded bytecode"""
+    import base64
+    import gzip
+    from spp import acir
+    prog = acir.load_program(doc)
+    raw = bytearray(prog.raw)
+    patch(raw, prog)
+    d = dict(doc)
+    d["bytecode"] = base64.b64encode(gzip.compress(bytes(raw))).decode()
+    return acir.load_program(d)
+
+
+def test_brillig_helpers_are_identified_by_content_not_by_id_or_shape(program, withdraw_kat):
+    """execute() used to pick the host helper by function id, to_blob() by call shape.  Both now ask
+    Program.brillig_kind: the unconstrained section must be the reference's own (sha256), and every call site must fit its helper.
+    (1) call sites with their function ids permuted, (2) a helper body that differs in one byte -- e.g. a 1 -> 1 function that is
+    not the inverse -- are unsupported-program errors in BOTH consumers, not wrong hints."""
+    import json
+    import struct
+    from spp import acir
+    from oracle import circuit as C
+    doc = json.load(open(os.path.join(GOLDEN, "reference_withdraw_acir.json")))
+    row = C.withdraw_inputs(withdraw_kat)
+    assert program.unconstrained_sha256 == acir.REFERENCE_UNCONSTRAINED_SHA256
+    calls = [(i, op) for i, op in enumerate(program.main.opcodes) if op[0] == "BrilligCall"]
+    assert sorted({op[1] for _, op in calls}) == [0, 1, 2] and len(program.main.brillig_id_offsets) == len(calls)
+    assert {program.brillig_kind(i, op[1], op[2], op[3]) for i, op in calls} == {"divmod", "inverse", "radix"}
+
+    def swap_ids(raw, prog):        # ids 0 <-> 1 at every call site: the divmod sites now name the inverse helper and vice versa
+        for off in prog.main.brillig_id_offsets:
+            (fid,) = struct.unpack_from("<I", raw, off)
+            if fid in (0, 1):
+                struct.pack_into("<I", raw, off, 1 - fid)
+    swapped = _patched_program(doc, swap_ids)
+    with pytest.raises(acir.AcirFormatError, match="shape"):
+        acir.execute(swapped, row)
+    with pytest.raises(acir.AcirFormatError, match="shape"):
+        acir.to_blob(swapped)
+
+    def other_body(raw, prog):      # one byte of a helper's bytecode: no longer the functions this module knows
+        raw[len(raw) - 40] ^= 1
+    changed = _patched_program(doc, other_body)
+    assert changed.unconstrained_sha256 != acir.REFERENCE_UNCONSTRAINED_SHA256
+    with pytest.raises(acir.AcirFormatError, match="not the reference's"):
+        acir.execute(changed, row)
+    with pytest.raises(acir.AcirFormatError, match="not the reference's"):
+        acir.to_blob(changed)
+    # the untouched program still executes and lowers
+    assert acir.execute(program, row) and len(acir.to_blob(program)) > 1000
+
+
 def test_witness_stack_round_trip_and_input_extraction(program, withdraw_kat, tmp_path):
     """target/<name>.gz (client/proof.helper.ts:58-66): writer and reader are inverse; the ABI inputs come back out of a
     full witness in Prover.toml order -- the row spp_prove_batch takes."""

@@ -157,9 +157,11 @@ def test_cpu_oracle_end_to_end(withdraw_artifacts, withdraw_kat):
     # the commitment hides: one committed wire is a mask derived from (r, s), so the commitment point itself (bytes 260..324)
     # changes with the blinding although the committed VALUES are the same
     assert proof3[260:324] != proof[260:324] and proof2[260:324] == proof[260:324]
-    from oracle.bn254 import hash_to_fr, DST_COMMITMENT
+    from oracle.bn254 import hash_to_fr, DST_COMMITMENT, DST_MASK
     mask_wire = c.program[c.program.index(C.OP_MASK) + 1]       # (no other instruction of this program has the operand value 12)
-    assert mask_wire in c.committed and wires[mask_wire] == hash_to_fr((11111).to_bytes(32, "big") + (22222).to_bytes(32, "big"), DST_COMMITMENT)[0]
+    rs_bytes = (11111).to_bytes(32, "big") + (22222).to_bytes(32, "big")
+    assert mask_wire in c.committed and wires[mask_wire] == hash_to_fr(rs_bytes, DST_MASK)[0]     # the mask's own domain ...
+    assert wires[mask_wire] != hash_to_fr(rs_bytes, DST_COMMITMENT)[0]                            # ... not the challenge's
     rows_with_mask = [k for k in range(c.n_constraints) if any(mask_wire in m.row(k)[0] for m in (c.A, c.B, c.C))]
     assert len(rows_with_mask) == 1 and c.A.row(rows_with_mask[0])[0] == (mask_wire,) and c.B.row(rows_with_mask[0])[0] == (0,)   # mask * 1 = mask
     assert p.prove([row[0] + 1] + row[1:], 1, 2)[0] == 1                     # unsatisfied -> refused

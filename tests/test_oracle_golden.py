@@ -131,3 +131,15 @@ def test_auditor_side_oracle(rlwe_vectors):
         assert rlwe.decode_owner(m) == (sum(b << (8 * i) for i, b in enumerate(v["msg"][:32])), sum(b << (8 * i) for i, b in enumerate(v["msg"][32:])))
     # rounding: exact ties go to the even neighbour, as Python's round()
     assert [round(x / 2) for x in (1, 3, 5, -1, -3)] == [0, 2, 2, 0, -2]
+
+
+def test_commitment_mask_has_a_domain_of_its_own():
+    """the hiding mask of the commitment (OP_MASK, fr.Hash of the blinding factors r || s) and the commitment challenge
+    (fr.Hash(Cm.x || Cm.y), gnark's tag "bsb22-commitment") are different protocol values: they are hashed under different
+    domain-separation tags, so the mask is not the challenge of the same 64 bytes; the C restatement derives the same mask."""
+    from oracle import circuit as C, bn254
+    r, s = 0x1234567890abcdef, 0xfedcba0987654321
+    msg = r.to_bytes(32, "big") + s.to_bytes(32, "big")
+    assert bn254.DST_MASK != bn254.DST_COMMITMENT and len(bn254.DST_MASK) == len(bn254.DST_COMMITMENT) == 16
+    assert C.mask_value(r, s) == bn254.hash_to_fr(msg, bn254.DST_MASK)[0]
+    assert C.mask_value(r, s) != bn254.hash_to_fr(msg, bn254.DST_COMMITMENT)[0]
