@@ -40,6 +40,21 @@ enum : uint32_t {
   OP_INV_H = 11,      // h out        : w[out] = 1 / <H_h,w>  (0 when the form is 0); an UNCONSTRAINED hint (ACIR Brillig inverse)
   OP_MASK = 12,       // out          : w[out] = fr.Hash(r || s): the random mask of the commitment (gnark: hints.Randomize inside
                       //                api.Commit) -- a committed wire no constraint touches, so that the commitment hides the others
+  // ---- the solver of a DECODED gnark system (spp/ccs.py to_sppc_solved): rows as gnark's solver uses them ----
+  OP_SOLVE_ROW = 13,  // k side inv odiv : the unknown is the LAST term of side (0 A, 1 B, 2 C) of row k, with coefficient cf:
+                      //                side 2: (<A><B> - rest) / cf;  side 0: (<C> / <B> - rest) / cf;  side 1: (<C> / <A> - rest) / cf.
+                      //                inv = index of 1/cf in coeffs (0xffffffff: cf = 1); odiv = index of the inverse of the other
+                      //                factor when that is a constant (0xffffffff: inverted at run time; a zero factor gives 0)
+  OP_LIMBS = 14,      // h n width out0 : out0+i = bits [i*width, (i+1)*width) of canonical(<H_h,w>), width <= 128; bit 31 of the width word:
+                      //                the limbs in reverse wire order
+                      //                (rangecheck.DecomposeHint, sw-grumpkin.decompose, the Brillig quotient / remainder by 2^128)
+  OP_COUNTN = 15,     // h0 n out0 size : out0+v = #{ i<n : canonical(<H_{h0+i},w>) == v }, v < size <= 256 (logderivarg.countHint
+                      //                over the table 0 .. size-1)
+  OP_GK_MUL = 16,     // h_lo h_hi gy out_x out_y out_inf : (lo + 2^128 hi) * G on Grumpkin, G = (1, coeffs[gy]); the ACIR MultiScalarMul
+                      //                black box over the generator: out = (x, y, 0), or (0, 0, 1) for the point at infinity
+  OP_GLV = 17,        // h out0 c[28] : sw-grumpkin.decomposeScalar: out0..+3 = 64-bit limbs of s1, out0+4..+7 of s2 (gnark_hints.hpp)
+  OP_EMUL = 18,       // h0 out0 c[16]: emulated.mulHint with b = 1, 64-bit limbs, 4-limb modulus q, 6 limb forms H_h0..: out0..+3 quotient,
+                      //                +4..+7 remainder, +8..+13 carries
 };
 
 enum : uint32_t { CIRCUIT_WITHDRAW = 1, CIRCUIT_AUDIT = 2, CIRCUIT_ACIR = 5 };

@@ -12,6 +12,7 @@
 #include "circuit.hpp"   // opcodes only
 #include "poseidon29.hpp"
 #include "lanes.hpp"
+#include "gnark_hints.hpp"
 #include "sha256.hpp"
 
 namespace spp {
@@ -326,6 +327,132 @@ __device__ __forceinline__ void solve_range(const DevCircuit& dc, Fr* __restrict
             *slot = *slot + one;
           }
         }
+        break;
+      }
+      case OP_SOLVE_ROW: {   // one row of a decoded gnark system solved for its last term of side `side`
+        const uint32_t k = pr[pc + 1], side = pr[pc + 2], inv_ci = pr[pc + 3], odiv_ci = pr[pc + 4];
+        pc += 5;
+        Fr v;
+        uint32_t out;
+        if (side == 2) {
+          const Fr a = dev_row_dot(dc.A, dc.coeffs, k, 0, W, P, p), b = dev_row_dot(dc.B, dc.coeffs, k, 0, W, P, p);
+          v = a * b - dev_row_dot(dc.C, dc.coeffs, k, 1, W, P, p);
+          out = dc.C.wire[dc.C.rowptr[k + 1] - 1];
+        } else {
+          const DevSparse& mine = side == 0 ? dc.A : dc.B;
+          const DevSparse& other = side == 0 ? dc.B : dc.A;
+          const Fr c = dev_row_dot(dc.C, dc.coeffs, k, 0, W, P, p);
+          Fr oi;
+          if (odiv_ci != 0xffffffffu) oi = dc.coeffs[odiv_ci];
+          else {
+            const Fr o = dev_row_dot(other, dc.coeffs, k, 0, W, P, p);
+            oi = o.is_zero() ? Fr::zero() : o.inv();
+          }
+          v = c * oi - dev_row_dot(mine, dc.coeffs, k, 1, W, P, p);
+          out = mine.wire[mine.rowptr[k + 1] - 1];
+        }
+        if (inv_ci != 0xffffffffu) v = v * dc.coeffs[inv_ci];
+        W[(size_t)out * P + p] = v;
+        last_k = 0xffffffffu;
+        break;
+      }
+      case OP_LIMBS: {
+        const uint32_t h = pr[pc + 1], nl = pr[pc + 2], width = pr[pc + 3] & 0x7fffffffu, out0 = pr[pc + 4];
+        const bool reversed = (pr[pc + 3] >> 31) != 0;      // limb i goes to out0 + n-1-i (a quotient stored in front of its remainder)
+        pc += 5;
+        uint32_t c[9];
+        dev_row_dot(dc.H, dc.coeffs, h, 0, W, P, p).to_canonical(c);
+        c[8] = 0;
+        // the canonical words go through the lane's scratch row (dynamic word indexing; a handful of calls per proof)
+        uint32_t* cw = reinterpret_cast<uint32_t*>(&scratch[(size_t)0 * P + p]);
+        SPP_UNROLL for (int i = 0; i < 8; i++) cw[i] = c[i];
+        for (uint32_t i = 0; i < nl; i++) {
+          uint32_t o[8];
+          SPP_UNROLL for (int j = 0; j < 8; j++) o[j] = 0;
+          for (uint32_t j = 0; j < 4 && 32 * j < width; j++) {
+            const uint32_t bit = i * width + 32 * j;
+            uint32_t v = 0;
+            if (bit < 256) {
+              const uint32_t wi = bit >> 5, sh = bit & 31;
+              v = cw[wi] >> sh;
+              if (sh && wi + 1 < 8) v |= cw[wi + 1] << (32 - sh);
+            }
+            const uint32_t left = width - 32 * j;
+            if (left < 32) v &= (1u << left) - 1u;
+            o[j] = v;
+          }
+          W[(size_t)(out0 + (reversed ? nl - 1 - i : i)) * P + p] = Fr::from_canonical(o);
+        }
+        break;
+      }
+      case OP_COUNTN: {
+        const uint32_t h0 = pr[pc + 1], n = pr[pc + 2], out0 = pr[pc + 3], size = pr[pc + 4];
+        pc += 5;
+        const Fr one = Fr::one();
+        for (uint32_t j = 0; j < size; j++) W[(size_t)(out0 + j) * P + p] = Fr::zero();
+        for (uint32_t i = 0; i < n; i++) {
+          uint32_t c[8];
+          dev_row_dot(dc.H, dc.coeffs, h0 + i, 0, W, P, p).to_canonical(c);
+          if (c[0] < size && (c[1] | c[2] | c[3] | c[4] | c[5] | c[6] | c[7]) == 0) {
+            Fr* slot = &W[(size_t)(out0 + c[0]) * P + p];
+            *slot = *slot + one;
+          }
+        }
+        break;
+      }
+      case OP_GK_MUL: {
+        const uint32_t hl = pr[pc + 1], hh = pr[pc + 2], gy = pr[pc + 3], ox = pr[pc + 4], oy = pr[pc + 5], oi = pr[pc + 6];
+        pc += 7;
+        uint32_t lo[8], hi[8], k[8];
+        dev_row_dot(dc.H, dc.coeffs, hl, 0, W, P, p).to_canonical(lo);
+        dev_row_dot(dc.H, dc.coeffs, hh, 0, W, P, p).to_canonical(hi);
+        SPP_UNROLL for (int i = 0; i < 4; i++) {
+          k[i] = lo[i];
+          k[4 + i] = hi[i];
+        }
+        Fr x = Fr::zero(), y = Fr::zero();
+        const bool fin = dev_grumpkin_mul(k, dc.coeffs[gy], &x, &y);
+        W[(size_t)ox * P + p] = x;
+        W[(size_t)oy * P + p] = y;
+        W[(size_t)oi * P + p] = fin ? Fr::zero() : Fr::one();
+        break;
+      }
+      case OP_GLV: {
+        const uint32_t h = pr[pc + 1], out0 = pr[pc + 2];
+        const uint32_t* kc = pr + pc + 3;
+        pc += 3 + 28;
+        uint32_t c[8], s1[4], s2[4];
+        dev_row_dot(dc.H, dc.coeffs, h, 0, W, P, p).to_canonical(c);
+        dev_glv_split(kc, c, s1, s2);
+        for (uint32_t i = 0; i < 2; i++) {
+          uint32_t o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+          o[0] = s1[2 * i]; o[1] = s1[2 * i + 1];
+          W[(size_t)(out0 + i) * P + p] = Fr::from_canonical(o);
+          o[0] = s2[2 * i]; o[1] = s2[2 * i + 1];
+          W[(size_t)(out0 + 4 + i) * P + p] = Fr::from_canonical(o);
+        }
+        for (uint32_t i = 2; i < 4; i++) {   // limbs 2, 3 of a value below 2^127: zero
+          W[(size_t)(out0 + i) * P + p] = Fr::zero();
+          W[(size_t)(out0 + 4 + i) * P + p] = Fr::zero();
+        }
+        break;
+      }
+      case OP_EMUL: {
+        const uint32_t h0 = pr[pc + 1], out0 = pr[pc + 2];
+        const uint32_t* qc = pr + pc + 3;
+        pc += 3 + 16;
+        uint32_t a[6][8], kq[8], rem[8];
+        for (uint32_t i = 0; i < 6; i++) dev_row_dot(dc.H, dc.coeffs, h0 + i, 0, W, P, p).to_canonical(a[i]);
+        Big384 carry[6];
+        dev_emulated_reduce<6, 6>(a, qc, kq, rem, carry);
+        for (uint32_t i = 0; i < 4; i++) {
+          uint32_t o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+          o[0] = kq[2 * i]; o[1] = kq[2 * i + 1];
+          W[(size_t)(out0 + i) * P + p] = Fr::from_canonical(o);
+          o[0] = rem[2 * i]; o[1] = rem[2 * i + 1];
+          W[(size_t)(out0 + 4 + i) * P + p] = Fr::from_canonical(o);
+        }
+        for (uint32_t i = 0; i < 6; i++) W[(size_t)(out0 + 8 + i) * P + p] = fr_from_bigs(carry[i]);
         break;
       }
       case OP_POSEIDON: {

@@ -1092,6 +1092,7 @@ static int load_circuit_impl(spp_ctx* ctx, const char* circuit_path, const char*
   }
   // program scan: split into sequential segments (one lane per proof) and wide steps (data-parallel instructions
   // that get their own kernels: batch divisions and lookup histograms), with the commitment boundary in between
+  bool generic_ops = false;
   {
     const auto& pr = circ.program;
     size_t pc = 0, seg = 0;
@@ -1138,13 +1139,20 @@ static int load_circuit_impl(spp_ctx* ctx, const char* circuit_path, const char*
           seg = pc;
           break;
         case OP_GRUMPKIN: pc += 5 + pr[pc + 4]; break;
+        // the solver of a decoded gnark system (spp/ccs.py to_sppc_solved): one lane per proof, whatever the batch size -- the
+        // cooperative planner knows nothing of these instructions
+        case OP_SOLVE_ROW: case OP_LIMBS: case OP_COUNTN: pc += 5; generic_ops = true; break;
+        case OP_GK_MUL: pc += 7; generic_ops = true; break;
+        case OP_GLV: pc += 3 + 28; generic_ops = true; break;
+        case OP_EMUL: pc += 3 + 16; generic_ops = true; break;
         default: return fail(SPP_ERR_FORMAT, "bad opcode %u in solver program", pr[pc]);
       }
     }
     flush(pc);
   }
 
-  if (int e = coop_plan(c)) return e;
+  if (generic_ops) c->no_coop = true;
+  else if (int e = coop_plan(c)) return e;
   if (int e = small_rows_plan(c)) return e;
 
   // ---- NTT tables ----

@@ -587,6 +587,305 @@ def to_sppc(system, c, path):
     return n
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# the decoded system WITH its solver: 26 withdraw inputs -> every wire on the device
+# ---------------------------------------------------------------------------------------------------------------------
+OP_BITS, OP_INV_H, OP_MASK = 4, 11, 12
+OP_SOLVE_ROW, OP_LIMBS, OP_COUNTN, OP_GK_MUL, OP_GLV, OP_EMUL = 13, 14, 15, 16, 17, 18
+NONE32 = 0xFFFFFFFF
+GRUMPKIN_GY = 17631683881184975370165255887551781615748388533673675138860
+LIMBS_REVERSED = 1 << 31
+
+
+def _glv_constants(lam=GLV_LAMBDA, q=Q_BASE):
+    """(v1, v2, det) of glv_split -- the reduced lattice basis depends on (q, lambda) alone -- as the 28 words OP_GLV carries"""
+    r0, r1, t0, t1 = q, lam % q, 0, 1
+    rows = []
+    while r1:
+        k = r0 // r1
+        r0, r1, t0, t1 = r1, r0 - k * r1, t1, t0 - k * t1
+        rows.append((r0, t0))
+    lim = 1 << (q.bit_length() // 2)
+    i = next(j for j, (r, _) in enumerate(rows) if r < lim)
+    v1, v2 = rows[i], rows[i + 1]
+    det = v1[0] * v2[1] - v2[0] * v1[1]
+    if det < 0:
+        v1, v2, det = v2, v1, -det
+    words = []
+    for v in (v1[0], v1[1], v2[0], v2[1]):
+        assert abs(v) < 1 << 128
+        words += [(abs(v) >> (32 * i)) & 0xFFFFFFFF for i in range(4)] + [1 if v < 0 else 0]
+    words += [(det >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+    return words
+
+
+class SolvedSystem:
+    """what to_sppc_solved derives: the wire permutation (gnark wire -> container wire), the solving steps and the container parts"""
+
+
+def plan_solver(system, c, program):
+    """The order in which every wire of the reference's system follows from the 26 ABI inputs: gnark's own rule -- a row with ONE
+    unknown wire defines it -- applied to ALL wires, the 6 184 ACIR witnesses included (in `sunspot prove` those come from `nargo
+    execute`; here the rows sunspot compiled from the same ACIR opcodes define them), plus the unconstrained helpers: the six Brillig
+    calls and the MultiScalarMul black box of the ACIR program, the 41 hint calls of the gnark system.  Returns the list of steps
+    ('acir', opcode index) | ('hint', hint index) | ('row', row, gnark wire, side) in a valid order; raises when a wire stays unknown."""
+    npub = len(c.public)
+    sec_index = {nm: npub + i for i, nm in enumerate(c.secret)}
+
+    def gw(acir_witness):        # gnark wire of an ACIR witness (None: the system does not use it)
+        flat_pub = len(program.main.public_parameters)
+        if acir_witness < flat_pub:
+            return 1 + acir_witness
+        return sec_index.get("__witness_%d" % acir_witness)
+
+    known = set(range(npub))
+    for _, ws in program.parameter_witnesses():
+        for x in ws:
+            if gw(x) is not None:
+                known.add(gw(x))
+
+    def expr_wires(e):
+        ws = set()
+        for _, a, b in e.mul_terms:
+            ws |= {a, b}
+        for _, a in e.linear:
+            ws.add(a)
+        return ws
+    acir_ops = []
+    for i, op in enumerate(program.main.opcodes):
+        if op[0] == "BrilligCall":
+            ins = set()
+            for inp in op[2]:
+                for e in ([inp[1]] if inp[0] == "single" else inp[1]):
+                    ins |= expr_wires(e)
+            outs = [x for o in op[3] for x in ([o[1]] if o[0] == "simple" else o[1])]
+            if any(gw(x) is not None for x in outs):
+                acir_ops.append((i, ins, outs))
+        elif op[0] == "MultiScalarMul":
+            acir_ops.append((i, {x[1] for x in op[2]}, list(op[4])))
+    steps = []
+    pending_acir, pending_hints = list(acir_ops), list(range(len(system.hints)))
+    work = set(range(len(system.rows)))
+    wires_of = [set(w for _, w in L + Rr + O) for (L, Rr, O) in system.rows]
+    progress = True
+    while progress:
+        progress = False
+        for op in list(pending_acir):
+            i, ins, outs = op
+            if all(gw(x) in known for x in ins):
+                for x in outs:
+                    if gw(x) is not None:
+                        known.add(gw(x))
+                steps.append(("acir", i))
+                pending_acir.remove(op)
+                progress = True
+        for hi in list(pending_hints):
+            _, _, _, ins, o0, o1 = system.hints[hi]
+            if all(w == CONST_WIRE or w in known for terms in ins for _, w in terms):
+                known.update(range(o0, o1))
+                steps.append(("hint", hi))
+                pending_hints.remove(hi)
+                progress = True
+        for k in sorted(work):
+            unk = wires_of[k] - known
+            if not unk:
+                work.discard(k)
+                continue
+            if len(unk) != 1:
+                continue
+            w = next(iter(unk))
+            sides = [any(x == w for _, x in side) for side in system.rows[k]]
+            if sum(sides) != 1:
+                continue
+            known.add(w)
+            work.discard(k)
+            steps.append(("row", k, w, sides.index(True)))
+            progress = True
+    if len(known) != system.n_wires or pending_hints:
+        raise ValueError("the solver plan leaves %d wires unknown" % (system.n_wires - len(known)))
+    return steps, gw
+
+
+def to_sppc_solved(system, c, program, path, circuit_id=CIRCUIT_CCS):
+    """The reference's R1CS as a container that carries its SOLVER: inputs are the 26 values of the withdraw ABI (5 public + 21
+    private, the order of client/proof.helper.ts:34-50), every other wire -- the 6 163 remaining ACIR witnesses and the 6 749 internal
+    wires -- is computed on the device by the program emitted here (plan_solver; new instructions OP_SOLVE_ROW .. OP_EMUL of
+    csrc/circuit.hpp).  Same rows as `to_sppc` (terms of a row reordered so that the wire a row defines comes last on its side,
+    duplicate wires of a side merged), wires renumbered: constant, 5 public, the 21 private inputs, then the rest in gnark's
+    order (+ one scratch wire no row touches, for hint outputs the system does not use).  Setup under the same seed gives the same
+    verifying key and, for the same (r, s) and mask, the same proof bytes as the all-inputs container -- what the tests compare.
+    circuit_id = 1 makes it a drop-in for generateProof / spp_prove_withdraw.  Returns (n_constraints, SolvedSystem)."""
+    steps, gw = plan_solver(system, c, program)
+    npub = len(c.public)
+    abi_secret = [gw(x) for _, ws in program.parameter_witnesses() for x in ws][npub - 1:]
+    assert len(abi_secret) == 21 and all(w is not None for w in abi_secret)
+    order = list(range(npub)) + abi_secret + [w for w in range(npub, system.n_wires) if w not in set(abi_secret)]
+    perm = {g: i for i, g in enumerate(order)}
+    trash = system.n_wires                       # one wire no constraint touches
+    n_wires = system.n_wires + 1
+    coef_index, coeffs = {}, []
+
+    def cid(v):
+        v %= R
+        if v not in coef_index:
+            coef_index[v] = len(coeffs)
+            coeffs.append(v)
+        return coef_index[v]
+
+    def merged(terms, last=None):
+        acc = {}
+        for cf, wi in terms:
+            acc[wi] = (acc.get(wi, 0) + cf) % R
+        items = [(wi, cf) for wi, cf in acc.items() if wi != last]
+        if last is not None:
+            items.append((last, acc[last]))
+        return items
+    defined = {}                                  # row -> (gnark wire, side)
+    for st in steps:
+        if st[0] == "row":
+            defined[st[1]] = (st[2], st[3])
+    rows_out = []
+    for k, row in enumerate(system.rows):
+        w, side = defined.get(k, (None, None))
+        rows_out.append([merged(row[sd], w if sd == side else None) for sd in range(3)])
+    hrows = []
+
+    def hrow(terms):
+        acc = {}
+        for cf, wi in terms:
+            key = 0 if wi == CONST_WIRE else perm[wi]
+            acc[key] = (acc.get(key, 0) + cf) % R
+        hrows.append([(wi, cf) for wi, cf in acc.items() if cf])
+        return len(hrows) - 1
+
+    def contiguous(gwires):
+        idx = [perm[g] for g in gwires]
+        if idx != list(range(idx[0], idx[0] + len(idx))):
+            raise ValueError("hint outputs are not consecutive wires")
+        return idx[0]
+    prog = []
+    chal = None
+    for st in steps:
+        if st[0] == "row":
+            _, k, w, side = st
+            cf = rows_out[k][side][-1][1]
+            if cf == 0:
+                raise ValueError("row %d: the wire it defines has coefficient 0" % k)
+            inv_ci = NONE32 if cf == 1 else cid(pow(cf, -1, R))
+            odiv = NONE32
+            if side != 2:
+                other = rows_out[k][1 - side]
+                if all(wi == 0 for wi, _ in other):
+                    val = sum(cf_ for _, cf_ in other) % R
+                    if val == 0:
+                        raise ValueError("row %d divides by the constant 0" % k)
+                    odiv = cid(pow(val, -1, R))
+            prog += [OP_SOLVE_ROW, k, side, inv_ci, odiv]
+        elif st[0] == "acir":
+            op = program.main.opcodes[st[1]]
+
+            def lin(e):
+                if e.mul_terms:
+                    raise ValueError("ACIR opcode %d: a helper input with a product term" % st[1])
+                return [(cf, gw(a)) for cf, a in e.linear] + [(e.constant, CONST_WIRE)]
+            if op[0] == "MultiScalarMul":
+                (_, lo), (_, hi) = op[2]
+                ox, oy, oi = (perm[gw(x)] if gw(x) is not None else trash for x in op[4])
+                prog += [OP_GK_MUL, hrow([(1, gw(lo))]), hrow([(1, gw(hi))]), cid(GRUMPKIN_GY), ox, oy, oi]
+                continue
+            kind = program.brillig_kind(st[1], op[1], op[2], op[3])
+            exprs = [i[1] for i in op[2]]
+            outs = [x for o in op[3] for x in ([o[1]] if o[0] == "simple" else o[1])]
+            if kind == "divmod":
+                if exprs[1].mul_terms or exprs[1].linear or exprs[1].constant != 1 << 128:
+                    raise ValueError("ACIR opcode %d: quotient / remainder by something else than 2^128" % st[1])
+                q_w, r_w = perm[gw(outs[0])], perm[gw(outs[1])]
+                if q_w + 1 == r_w:      # limb 0 (the remainder) goes to the HIGHER wire
+                    prog += [OP_LIMBS, hrow(lin(exprs[0])), 2, 128 | LIMBS_REVERSED, q_w]
+                elif r_w + 1 == q_w:
+                    prog += [OP_LIMBS, hrow(lin(exprs[0])), 2, 128, r_w]
+                else:
+                    raise ValueError("ACIR opcode %d: quotient and remainder are not neighbouring wires" % st[1])
+            elif kind == "inverse":
+                prog += [OP_INV_H, hrow(lin(exprs[0])), perm[gw(outs[0])] if gw(outs[0]) is not None else trash]
+            else:                       # radix 2
+                if exprs[2].constant != 2 or exprs[1].constant != len(outs):
+                    raise ValueError("ACIR opcode %d: radix decomposition other than bits" % st[1])
+                prog += [OP_BITS, hrow(lin(exprs[0])), len(outs), contiguous([gw(x) for x in outs])]
+        else:
+            _, _, name, ins, o0, o1 = system.hints[st[1]]
+            short = name.rsplit("/", 1)[-1]
+            n_out = o1 - o0
+            const = lambda terms: sum(cf for cf, _ in terms) % R if all(w == CONST_WIRE for _, w in terms) else None
+            if short == "bits.nBits":
+                prog += [OP_BITS, hrow(ins[0]), n_out, contiguous(range(o0, o1))]
+            elif short == "rangecheck.DecomposeHint":
+                width = const(ins[1])
+                prog += [OP_LIMBS, hrow(ins[2]), n_out, width, contiguous(range(o0, o1))]
+            elif short == "sw-grumpkin.decompose":
+                prog += [OP_LIMBS, hrow(ins[0]), n_out, 64, contiguous(range(o0, o1))]
+            elif short == "solver.InvZeroHint":
+                assert n_out == 1 and len(ins) == 1
+                prog += [OP_INV_H, hrow(ins[0]), perm[o0]]
+            elif short == "logderivarg.countHint":
+                size, width = const(ins[0]), const(ins[1])
+                if width != 1 or [const(t) for t in ins[2:2 + size]] != list(range(size)) or n_out != size or size > 256:
+                    raise ValueError("countHint over a table that is not 0 .. size-1")
+                q = ins[2 + size:]
+                h0 = hrow(q[0])
+                for t in q[1:]:
+                    hrow(t)
+                prog += [OP_COUNTN, h0, len(q), contiguous(range(o0, o1)), size]
+            elif short == "sw-grumpkin.decomposeScalar":
+                nl, bits = const(ins[7]), const(ins[8])
+                q = sum(const(t) << (bits * i) for i, t in enumerate(ins[9:9 + nl]))
+                if (nl, bits, q, n_out) != (4, 64, Q_BASE, 8):
+                    raise ValueError("decomposeScalar with an unexpected layout")
+                prog += [OP_GLV, hrow(ins[6]), contiguous(range(o0, o1))] + _glv_constants()
+            elif short == "emulated.mulHint":
+                bits, n, na, nq = (const(ins[i]) for i in range(4))
+                p_l = [const(t) for t in ins[4:4 + n]]
+                b_l = [const(t) for t in ins[4 + n + na:]]
+                if (bits, n, na, nq, b_l, n_out) != (64, 4, 6, 4, [1], 14) or sum(v << (64 * i) for i, v in enumerate(p_l)) != Q_BASE:
+                    raise ValueError("emulated.mulHint with an unexpected layout")
+                a_rows = ins[4 + n:4 + n + na]
+                h0 = hrow(a_rows[0])
+                for t in a_rows[1:]:
+                    hrow(t)
+                qinv = pow(Q_BASE, -1, 1 << 256)
+                prog += [OP_EMUL, h0, contiguous(range(o0, o1))] + [(Q_BASE >> (32 * i)) & 0xFFFFFFFF for i in range(8)] + \
+                        [(qinv >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+            elif short == "hints.Randomize":
+                prog += [OP_MASK, perm[o0]]
+            elif short == "cs.Bsb22CommitmentComputePlaceholder":
+                prog += [OP_COMMIT]
+                chal = perm[o0]
+            else:
+                raise ValueError("hint %s has no device implementation" % short)
+    prog.append(OP_END)
+
+    def sparse(rows):
+        rowptr, flat = [0], []
+        for terms in rows:
+            for wi, cf in terms:
+                flat += [wi, cid(cf)]
+            rowptr.append(len(flat) // 2)
+        return struct.pack("<2I", len(rows), len(flat) // 2) + struct.pack("<%dI" % len(rowptr), *rowptr) + struct.pack("<%dI" % len(flat), *flat)
+    mats = [sparse([[(perm[wi], cf) for wi, cf in r[sd]] for r in rows_out]) for sd in range(3)] + [sparse(hrows)]
+    committed = [perm[w] for w in c.meta["CommitmentInfo"].value[0]["PrivateCommitted"]]
+    n = len(system.rows)
+    domain_log = max(1, (n - 1).bit_length())
+    head = struct.pack("<13I", SPPC_MAGIC, SPPC_VERSION, circuit_id, npub, 21, n_wires, n, domain_log, chal, len(coeffs), len(committed),
+                       len(prog), 0)
+    body = b"".join(v.to_bytes(32, "little") for v in coeffs) + b"".join(mats) + struct.pack("<%dI" % len(committed), *committed) + \
+        struct.pack("<%dI" % len(prog), *prog)
+    with open(path, "wb") as f:
+        f.write(head + body)
+    ss = SolvedSystem()
+    ss.perm, ss.order, ss.steps, ss.program, ss.hrows, ss.rows, ss.trash, ss.challenge_wire = perm, order, steps, prog, hrows, rows_out, trash, chal
+    return n, ss
+
+
 def reference_witness(system, c, public_inputs, secret_by_name, challenge_of_row):
     """The full assignment of the reference's system as the input row of the container `to_sppc` writes (wires 1 .. n-1).
     challenge_of_row(row with unknown wires as 0) -> commitment challenge (CircuitHandle.commitment_challenge on the GPU)."""

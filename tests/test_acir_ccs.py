@@ -404,6 +404,76 @@ def test_reference_r1cs_is_proved_on_the_gpu(program, withdraw_kat, tmp_path):
         ctx.close()
 
 
+def test_solver_plan_of_the_reference_r1cs(program):
+    """spp/ccs.py plan_solver: from the 26 ABI inputs every one of the 12 939 wires follows by gnark's own rule (a row with one
+    unknown wire defines it) plus the 41 hint calls and the ACIR program's unconstrained helpers; the emitted container holds
+    the same 12 452 rows and a program of the new solver instructions only."""
+    from spp import ccs
+    c = ccs.load_ccs(os.path.join(GOLDEN, "reference_withdraw.ccs"))
+    s = ccs.decode_system(c)
+    steps, _ = ccs.plan_solver(s, c, program)
+    kinds = {}
+    for st in steps:
+        kinds[st[0]] = kinds.get(st[0], 0) + 1
+    assert kinds["hint"] == 41 and kinds["acir"] == 7 and kinds["row"] > 12000          # 6 Brillig calls + the MultiScalarMul
+    defined = {st[2] for st in steps if st[0] == "row"}
+    assert len(defined) == kinds["row"]                       # one wire per defining row
+
+
+@pytest.mark.gpu
+def test_reference_r1cs_is_solved_and_proved_on_the_gpu_from_the_26_inputs(program, withdraw_kat, tmp_path):
+    """the reference's own constraint system with its SOLVER on the device (spp/ccs.py to_sppc_solved): the
+    container takes the 26 withdraw inputs of client/proof.helper.ts:34-50.  (1) every wire the device computes == gnark's
+    solver loop restated in spp/ccs.py solve_partial (fed by this repository's ACIR executor) on the reference KAT and on fresh
+    notes with keys on both sides of 2^127 (the scalar decomposition's non-trivial half); (2) same verifying key and byte-identical
+    proofs as the ORACLE proving the all-inputs container of the same system from solve_partial's witness, same seed, blinding
+    and mask; (3) a batch of 64 distinct notes verifies; bad inputs are refused in place."""
+    import spp
+    from spp import ccs, acir
+    from oracle import circuit as C, native, groth16
+    c, s, pure = _reference_system(tmp_path)
+    solved = str(tmp_path / "solved.sppc")
+    n, ss = ccs.to_sppc_solved(s, c, program, solved)
+    assert n == 12452
+    pk, vk, opk, ovk = (str(tmp_path / x) for x in ("s.pk", "s.vk", "o.pk", "o.vk"))
+    seed = b"\x0b" * 32
+    ctx = spp.Context(0)
+    try:
+        ctx.setup(solved, seed, pk, vk)
+        native.setup(pure, seed, opk, ovk)
+        assert open(vk, "rb").read() == open(ovk, "rb").read()          # the same statement under the same toxic waste
+        orc = native.Prover(pure, opk)
+        h = ctx.load_circuit(solved, pk, 6)
+        try:
+            assert h.n_inputs == 26 and h.n_wires == s.n_wires + 1 and h.n_constraints == 12452
+            rows = [C.withdraw_inputs(withdraw_kat)] + [_fresh_note_inputs(k) for k in range(20, 25)]
+            assert any(r[5] >> 127 for r in rows) and any(not (r[5] >> 127) for r in rows)
+            for i, row in enumerate(rows):
+                r_, s_ = 1000003 * i + 17, (1 << 200) + 29 * i
+                proofs, pws, status = h.prove_batch([row], [(r_, s_)])
+                assert status == [0]
+                dev = h.debug_witness()
+                wa = acir.execute(program, row)
+                ref, st = ccs.solve_partial(s, c, row[:5], {"__witness_%d" % k: v for k, v in wa.items()}, challenge=dev[ss.challenge_wire],
+                                            randomizer=C.mask_value(r_, s_))
+                assert not st["rows_unsatisfied"] and not st["rows_skipped"] and not st["hints_skipped"]
+                assert [dev[ss.perm[g]] for g in range(s.n_wires)] == ref, i        # every wire
+                rc, proof, pw = orc.prove(ref[1:], r_, s_)
+                assert rc == 0 and proofs[0] == proof and pws[0] == pw, i           # same bytes as the oracle on the all-inputs system
+                assert groth16.verify(open(vk, "rb").read(), proofs[0], pws[0])
+            batch = [_fresh_note_inputs(100 + k) for k in range(64)]
+            bad = list(batch[7]); bad[3] += 1                                       # amount
+            batch[7] = bad
+            proofs, pws, status = h.prove_batch(batch, [(3 * k + 1, 5 * k + 2) for k in range(64)])
+            assert [k for k in range(64) if status[k] != 0] == [7]
+            good = [k for k in range(64) if k != 7]
+            assert all(ctx.verify_batch(open(vk, "rb").read(), [proofs[k] for k in good], [pws[k] for k in good]))
+        finally:
+            h.close()
+    finally:
+        ctx.close()
+
+
 def test_fixtures_equal_the_reference_files():
     ref = "/root/reference/noir_circuit/target"
     if not os.path.exists(ref):
