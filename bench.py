@@ -655,36 +655,28 @@ def main():
         return out
 
     strong = args.mode == "strong"
-    def reference_r1cs_leg(B=64, steps=10, warmup=3):
+    def reference_r1cs_leg(B=2048, steps=10, warmup=3):
         """the reference's OWN gnark constraint system (tests/golden/reference_withdraw.ccs = noir_circuit/target/
-        shielded_pool_verifier.ccs) set up and proved on the GPU.  Its witness is completed on the host by gnark's solver loop
-        (spp/ccs.py; a process pool here), the commitment challenge comes from spp_commitment_challenge; the timed region is the GPU
-        part, rows resident in HBM, as for every other leg.  B distinct notes."""
-        import multiprocessing as mp
-        from spp import ccs
+        shielded_pool_verifier.ccs) solved AND proved on the GPU: the container spp/ccs.py to_sppc_solved writes takes the 26 withdraw
+        inputs of client/proof.helper.ts:34-50; the 6 163 other ACIR witnesses (`nargo execute` in the reference) and the 6 749
+        internal wires (gnark's solver with its nine hints) are computed by the device solver inside the timed region.  B distinct
+        notes per step, rows resident in HBM when the clock starts, as for every other leg."""
+        from spp import ccs, acir
         golden = os.path.join(ROOT, "tests", "golden")
         ccs_path, acir_path = os.path.join(golden, "reference_withdraw.ccs"), os.path.join(golden, "reference_withdraw_acir.json")
         tmp = tempfile.mkdtemp(prefix="spp_bench_ccs_")
         sppc, pkp, vkp = (os.path.join(tmp, "c." + e) for e in ("sppc", "pk", "vk"))
         c = ccs.load_ccs(ccs_path)
         system = ccs.decode_system(c)
-        n_rows = ccs.to_sppc(system, c, sppc)
+        n_rows, solved = ccs.to_sppc_solved(system, c, acir.load_program(acir_path), sppc)
         ctx = spp.Context(local_rank)
         ctx.setup(sppc, b"\x2a" * 32, pkp, vkp)
         t0 = time.time()
         h = ctx.load_circuit(sppc, pkp, args.window)
         load_s = time.time() - t0
+        assert h.n_inputs == 26
         notes = workload.withdraw_rows(ctx, B, seed=91)               # distinct notes of one tree; keys below 2^128
-        rows = [workload.row_ints(notes, 26, i) for i in range(B)]
-        t0 = time.time()
-        with mp.get_context("spawn").Pool(min(16, os.cpu_count() or 1)) as pool:
-            import secrets
-            masks = [secrets.randbelow(ccs.R) for _ in rows]          # gnark's hints.Randomize: the commitment's hiding mask
-            first = pool.map(ccs.complete_witness_worker, [(ccs_path, acir_path, r, None, m) for r, m in zip(rows, masks)])
-            chal = h.commitment_challenge(b"".join(first))
-            full = pool.map(ccs.complete_witness_worker, [(ccs_path, acir_path, r, ch, m) for r, ch, m in zip(rows, chal, masks)])
-        witness_s = time.time() - t0
-        inp = torch.frombuffer(bytearray(b"".join(full)), dtype=torch.uint8).to(dev)
+        inp = torch.frombuffer(bytearray(notes), dtype=torch.uint8).to(dev)
         import random as _r
         rng = _r.Random(4)
         R_ = 21888242871839275222246405745257275088548364400416034343698204186575808495617
@@ -704,6 +696,7 @@ def main():
             step(k)
         h.sync(); torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        stages = h.last_timings(0)
         pr, pw, st = outs[(warmup + steps - 1) & 1]
         assert int(st.abs().sum().item()) == 0
         pb, wb = pr.cpu().numpy().tobytes(), pw.cpu().numpy().tobytes()
@@ -717,13 +710,16 @@ def main():
             lat.append((time.perf_counter() - tl) * 1e3)
         res = {"value": round(B * steps / elapsed, 1), "unit": "proofs/s", "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "warmup": warmup,
                "config": {"workload": "the reference's own gnark R1CS (noir_circuit/target/shielded_pool_verifier.ccs decoded by spp/ccs.py: 12 452 rows, "
-                                      "41 hint calls, 657 levels), batch of %d distinct notes; witnesses completed on the host by gnark's solver loop, "
-                                      "rows resident in HBM when the clock starts" % B,
-                          "n_constraints": n_rows, "n_wires": system.n_wires, "domain": 1 << 14, "batch_per_gpu": B, "n_distinct_witnesses": len(set(full)),
-                          "host_witness_completion_s": round(witness_s, 1), "load_s": round(load_s, 2),
+                                      "41 hint calls), batch of %d distinct notes; the clock starts at the 26 withdraw inputs resident in HBM: all 12 939 "
+                                      "wires are solved on the device (the reference runs `nargo execute` + gnark's solver for them)" % B,
+                          "n_constraints": n_rows, "n_wires": system.n_wires, "domain": 1 << 14, "batch_per_gpu": B, "n_inputs": 26,
+                          "solver_program_words": len(solved.program), "load_s": round(load_s, 2),
+                          "msm_windows": dict(zip(INFO_ORDER, h.msm_windows())), "table_bytes": h.table_bytes,
+                          "stage_ms_last_step": {k: round(v, 3) for k, v in zip(["solve+commit", "matrix_eval", "ntt_qap", "msm_g1", "join", "assemble", "total"], stages[:7])},
                           "verified": "all %d proofs of the last batch by spp_verify_batch, one by spp_verify" % B},
                "single_proof_latency_ms": round(sorted(lat[2:])[len(lat[2:]) // 2], 3)}
         h.close(); ctx.close()
+        torch.cuda.empty_cache()
         return res
 
     def coresident_leg(Bp=2048, steps=10, warmup=3, budget=228e9):
