@@ -90,6 +90,8 @@ struct spp_circuit {
   uint32_t c_bits = 10, n = 0, logn = 0;
   uint32_t max_batch_div = SOLVE_SCRATCH_MIN_ROWS;
   DevCoop coop{};
+  bool generic_solver = false;    // the program is the solver of a decoded gnark system (OP_SOLVE_ROW ...): ~12 K dependent row solves per
+                                  // proof on one lane -- a batch's solver phase outlasts the rest of it, so three batches take turns
   bool no_coop = false;           // SPP_NO_COOP=1 (diagnostic): always the one-lane-per-proof solver
   bool trace_items = false;       // SPP_COOP_TRACE=1 (diagnostic): one launch per item of the cooperative solver
   bool one_track = false;         // SPP_COOP_ONE_TRACK=1 (diagnostic): the independent tracks of a stretch one after the other
@@ -1151,6 +1153,7 @@ static int load_circuit_impl(spp_ctx* ctx, const char* circuit_path, const char*
     flush(pc);
   }
 
+  c->generic_solver = generic_ops;
   if (generic_ops) c->no_coop = true;
   else if (int e = coop_plan(c)) return e;
   if (int e = small_rows_plan(c)) return e;
@@ -1529,14 +1532,14 @@ static int prove_on_device(spp_circuit* c, Workspace& w, uint32_t P, const uint8
   return SPP_OK;
 }
 
-static int ws_depth(size_t count) {
+static int ws_depth(size_t count, bool generic_solver = false) {
   static const int forced = [] {   // SPP_DEPTH (experiment): batches in flight, 1 .. SPP_NWS
     const char* e = getenv("SPP_DEPTH");
     const int v = e ? atoi(e) : 0;
     return v >= 1 && v <= SPP_NWS ? v : 0;
   }();
   if (forced) return forced;
-  return count <= 256 ? 4 : count <= 768 ? 3 : 2;
+  return count <= 256 ? 4 : (count <= 768 || generic_solver) ? 3 : 2;
 }
 extern "C" int spp_prove_batch_device(spp_circuit* c, size_t count, const void* d_inputs, const void* d_rs, void* d_proofs, void* d_pws,
                                       void* d_status) {
@@ -1548,7 +1551,7 @@ extern "C" int spp_prove_batch_device(spp_circuit* c, size_t count, const void* 
   // Batches in flight: two for big batches (more adds nothing once the latency-bound phases are covered: DESIGN 8.3); small
   // batches -- 128 proofs are one of 8 ranks' share of BASELINE.json configs[2] -- spend a larger part of their time in
   // latency-bound kernels (11 ms of sponge chain in the solver, the Horner combines), so up to four take turns.
-  const int depth = ws_depth(count);
+  const int depth = ws_depth(count, c->generic_solver);
   if (c->next_ws >= depth) c->next_ws = 0;
   const int wi = c->next_ws, wo = (wi + 1) % depth;
   Workspace& w = c->ws[wi];
