@@ -60,6 +60,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline circuit only (profiling runs)")
     ap.add_argument("--no-other-circuits", action="store_true", help="headline circuit with its own legs (rehearsal, end to end), none of the other circuits / configs")
+    ap.add_argument("--msm-shard-leg", action="store_true", help="N > 1: also run the 2^24-point MSM cut over the GPUs (BASELINE configs[4], SURVEY 8e)")
+    ap.add_argument("--msm-shard-leg-only", action="store_true", help="only that leg")
+    ap.add_argument("--msm-points", type=int, default=1 << 24)
     ap.add_argument("--pair-leg-only", action="store_true", help="diagnostic: only the leg with both circuits resident")
     ap.add_argument("--ccs-leg-only", action="store_true", help="diagnostic: only the leg that proves the reference's own gnark R1CS")
     ap.add_argument("--no-single", action="store_true", help="skip the single-proof latency leg (keeps profiler per-kernel averages clean)")
@@ -806,6 +809,44 @@ def main():
         torch.cuda.empty_cache()
         return res
 
+    def sharded_msm_leg(npts=1 << 24, iters=10):
+        """BASELINE.json configs[4] on N GPUs: the 2^24 points cut into contiguous shares, one partial sum per rank, ONE
+        all_gather of 64-byte points over RCCL, the sum on every rank (spp/multi.py msm_g1_sharded).  Opt-in (--msm-shard-leg): the
+        default multi-GPU run is the proving benchmark alone."""
+        from spp.multi import msm_g1_sharded
+        ctxm = spp.Context(local_rank)
+        it_ms = {}
+
+        def partial(lo, hi):
+            outb, ms, _ = ctxm.msm_g1_pippenger_bench_shard(npts, lo, hi - lo, seed=5, iters=iters)
+            it_ms["ms"] = ms
+            return outb
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        tg = time.perf_counter()
+        total_pt = msm_g1_sharded(dist, npts, partial, lambda parts: ctxm.msm_g1(b"".join(parts), [1] * len(parts)), coll_dev)
+        torch.cuda.synchronize()
+        slowest = it_ms.get("ms", 0.0)
+        if dist is not None:
+            dist.barrier()
+            tms = torch.tensor([slowest], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(tms, op=dist.ReduceOp.MAX)
+            slowest = float(tms.item())
+        wall = time.perf_counter() - tg
+        ctxm.close()
+        return {"metric": "G1 MSM points/sec (Pippenger, general bases), points cut over the GPUs", "n_gpus": world,
+                "ms_per_msm_slowest_rank": round(slowest, 3), "value": round(npts / (slowest * 1e-3), 1) if slowest else None,
+                "unit": "points/s", "iters": iters, "points": npts, "result_hex": total_pt.hex(),
+                "exchange": "one all_gather of %d x 64 B partial sums" % world, "wall_s_including_base_generation": round(wall, 2)}
+
+    if args.msm_shard_leg_only:
+        leg = sharded_msm_leg(npts=args.msm_points)
+        if rank == 0:
+            print(json.dumps({"msm_g1_sharded": leg}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     if args.pair_leg_only:
         print(json.dumps({"audit_plus_withdraw_coresident": coresident_leg()}), flush=True)
         return
@@ -835,6 +876,10 @@ def main():
         extras["rlwe_witness_2p16"] = rlwe_leg(ctx, dev, rlwe_pk)
         extras["msm_g1_2p24"] = pippenger_leg(ctx)
         ctx.close()
+    if world > 1 and args.msm_shard_leg and not strong:
+        leg = sharded_msm_leg()
+        if rank == 0:
+            extras["msm_g1_2p24_sharded"] = leg
     if rank == 0:
         line = {"metric": "Groth16 proofs/sec", "value": main_res["value"], "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": args.mode,

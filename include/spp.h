@@ -278,6 +278,11 @@ int spp_msm_g1_pippenger_bench(spp_ctx* ctx, size_t n, uint64_t seed, const uint
  * 70 % of a gnark witness is small), the rest uniform. */
 int spp_msm_g1_pippenger_bench_dist(spp_ctx* ctx, size_t n, uint64_t seed, uint32_t small_permille, const uint8_t scale_be[32], int iters,
                                     uint8_t out[64], float* ms_total, float* ms_bucket_kernel);
+/* Points [first, first + count) of the same n_total-point synthetic MSM: what one of N ranks computes when the 2^24 points of
+ * BASELINE.json configs[4] are cut over the GPUs of a node; the N partial sums are gathered and added by the caller
+ * (spp/multi.py msm_g1_sharded).  out = this share's partial sum. */
+int spp_msm_g1_pippenger_bench_shard(spp_ctx* ctx, size_t n_total, size_t first, size_t count, uint64_t seed, uint32_t small_permille,
+                                     const uint8_t scale_be[32], int iters, uint8_t out[64], float* ms_total, float* ms_bucket_kernel);
 
 #ifdef __cplusplus
 }

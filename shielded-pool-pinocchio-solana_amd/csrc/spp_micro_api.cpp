@@ -114,26 +114,40 @@ extern "C" int spp_msm_g1_pippenger_bench(spp_ctx* ctx, size_t n, uint64_t seed,
 }
 extern "C" int spp_msm_g1_pippenger_bench_dist(spp_ctx* ctx, size_t n, uint64_t seed, uint32_t small_permille, const uint8_t scale_be[32],
                                                int iters, uint8_t out[64], float* ms_total, float* ms_bucket_kernel) {
-  if (!ctx || !out || n == 0 || iters <= 0 || small_permille > 1000) return fail(SPP_ERR_BAD_INPUT, "bad argument");
-  if (n > (1u << 26)) return fail(SPP_ERR_BAD_INPUT, "n too large");
+  return spp_msm_g1_pippenger_bench_shard(ctx, n, 0, n, seed, small_permille, scale_be, iters, out, ms_total, ms_bucket_kernel);
+}
+// The same synthetic MSM cut over GPUs (BASELINE.json configs[4] on N GPUs): points [first, first + count) of the SAME
+// n_total-point sequence -- every rank proves its contiguous share, the N partial sums (64 B each) are gathered and added
+// (spp/multi.py msm_g1_sharded).  out = the partial sum of the share.
+extern "C" int spp_msm_g1_pippenger_bench_shard(spp_ctx* ctx, size_t n_total, size_t first, size_t count, uint64_t seed, uint32_t small_permille,
+                                                const uint8_t scale_be[32], int iters, uint8_t out[64], float* ms_total,
+                                                float* ms_bucket_kernel) {
+  if (!ctx || !out || n_total == 0 || count == 0 || first + count > n_total || iters <= 0 || small_permille > 1000)
+    return fail(SPP_ERR_BAD_INPUT, "bad argument");
+  if (n_total > (1u << 26)) return fail(SPP_ERR_BAD_INPUT, "n too large");
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
-  // host-generated scalars (n * 32 B; 512 MiB at 2^24) uploaded once
+  const size_t n = count;
+  // host-generated scalars (n * 32 B; 512 MiB at 2^24) uploaded once; the generator is stepped through the points before `first`
   std::vector<Fr> ks(n), sc(n);
   uint64_t x = seed * 6364136223846793005ull + 1442695040888963407ull;
   auto next = [&]() { x = x * 6364136223846793005ull + 1442695040888963407ull; return x; };
   Fr scale = Fr::one();
   if (scale_be) scale = Fr::from_bytes_be(scale_be);
-  for (size_t i = 0; i < n; i++) {
-    ks[i] = Fr::from_u64(next() | 1);
+  for (size_t gi = 0; gi < first + n; gi++) {
+    const uint64_t kv = next() | 1;
     uint32_t w[8];
     for (int k = 0; k < 8; k += 2) { uint64_t v = next(); w[k] = (uint32_t)v; w[k + 1] = (uint32_t)(v >> 32); }
+    const bool small = small_permille && (next() >> 20) % 1000 < small_permille;
+    if (gi < first) continue;
+    const size_t i = gi - first;
+    ks[i] = Fr::from_u64(kv);
     w[7] &= 0x1fffffffu;   // < 2^253 < r
     Fr s;
     for (int k = 0; k < 8; k++) s.l[k] = w[k];
     // witness-like: a byte-sized VALUE (Config 5); the uniform ones are raw words of a random element anyway
-    if (small_permille && (next() >> 20) % 1000 < small_permille) s = Fr::from_u64(w[0] & 0xffu);
+    if (small) s = Fr::from_u64(w[0] & 0xffu);
     sc[i] = scale_be ? s * scale : s;   // both are fixed representations of the same field element family
   }
   DevBuf dk, ds, dp, dw, dt, dg, dtmp, dpre;

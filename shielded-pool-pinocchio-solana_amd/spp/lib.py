@@ -106,6 +106,8 @@ def load_library():
     L.spp_msm_g1_pippenger_bench.argtypes = [vp, sz, ctypes.c_uint64, cp, i32, vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     L.spp_msm_g1_pippenger_bench_dist.argtypes = [vp, sz, ctypes.c_uint64, ctypes.c_uint32, cp, i32, vp, ctypes.POINTER(ctypes.c_float),
                                                   ctypes.POINTER(ctypes.c_float)]
+    L.spp_msm_g1_pippenger_bench_shard.argtypes = [vp, sz, sz, sz, ctypes.c_uint64, ctypes.c_uint32, cp, i32, vp, ctypes.POINTER(ctypes.c_float),
+                                                   ctypes.POINTER(ctypes.c_float)]
     _LIB = L
     return L
 

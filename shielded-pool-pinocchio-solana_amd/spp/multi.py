@@ -27,3 +27,26 @@ def broadcast_blob(dist, blob, src=0, device="cpu"):
         data = torch.empty(int(size.item()), dtype=torch.uint8, device=device)
     dist.broadcast(data, src)
     return bytes(data.cpu().numpy().tobytes())
+
+
+def gather_blobs(dist, blob, device="cpu"):
+    """all_gather of equal-length bytes objects: the list of every rank's blob, in rank order, on every rank."""
+    import torch
+    mine = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
+    parts = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, mine)
+    return [bytes(p.cpu().numpy().tobytes()) for p in parts]
+
+
+def msm_g1_sharded(dist, n, partial_fn, sum_fn, device="cpu"):
+    """One large G1 MSM over the GPUs of a node (SURVEY 8e for BASELINE.json configs[4]: "shard the 2^24 points 8-way, gather 8
+    partial sums"): rank r computes the partial sum of its contiguous share of the points -- partial_fn(lo, hi) -> 64 B, on the GPU:
+    Context.msm_g1_pippenger_bench_shard -- the world_size partial sums (64 B each: the ONLY exchange, one all_gather over RCCL / xGMI)
+    are added on every rank by sum_fn(list of 64 B) -> 64 B (on the GPU: Context.msm_g1 with unit scalars).  Without a process group
+    (dist None) it is the plain MSM."""
+    if dist is None:
+        return partial_fn(0, n)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lo, hi = shard_range(n, rank, world)
+    part = partial_fn(lo, hi) if hi > lo else bytes(64)
+    return sum_fn(gather_blobs(dist, part, device))

@@ -126,6 +126,16 @@ class Context:
         return out.raw, t.value, k.value
 
 
+    def msm_g1_pippenger_bench_shard(self, n_total, first, count, seed=5, scale=None, iters=1, small_permille=0):
+        """The partial sum of points [first, first + count) of the n_total-point synthetic MSM (one rank's share): (bytes, ms, bucket ms)."""
+        out = ctypes.create_string_buffer(64)
+        t, k = ctypes.c_float(0), ctypes.c_float(0)
+        sb = None if scale is None else int(scale).to_bytes(32, "big")
+        check(self.L.spp_msm_g1_pippenger_bench_shard(self.h, n_total, first, count, seed, int(small_permille), sb, iters,
+                                                      ctypes.cast(out, ctypes.c_void_p), ctypes.byref(t), ctypes.byref(k)))
+        return out.raw, t.value, k.value
+
+
 class CircuitHandle:
     def __init__(self, ctx, circuit_path, pk_path, window_bits=0, bits=None):
         self.ctx = ctx

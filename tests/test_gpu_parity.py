@@ -847,6 +847,18 @@ def test_pippenger_matches_oracle_and_is_linear(ctx):
     assert r3 == out.raw
 
 
+def test_pippenger_shards_add_up_to_the_whole_msm(ctx):
+    """spp_msm_g1_pippenger_bench_shard: the partial sums of three uneven contiguous shares of the synthetic 2^16-point MSM add up to
+    the MSM of all points (what spp/multi.py msm_g1_sharded gathers over RCCL on a multi-GPU node), and a share of everything is the
+    unsharded entry point's result."""
+    n = 1 << 16
+    whole, _, _ = ctx.msm_g1_pippenger_bench(n, seed=9)
+    assert ctx.msm_g1_pippenger_bench_shard(n, 0, n, seed=9)[0] == whole
+    cuts = [0, 20000, 20001, n]
+    parts = [ctx.msm_g1_pippenger_bench_shard(n, cuts[i], cuts[i + 1] - cuts[i], seed=9)[0] for i in range(3)]
+    assert ctx.msm_g1(b"".join(parts), [1, 1, 1]) == whole
+
+
 def test_pippenger_skewed_scalars(ctx):
     """Witness-like distributions (SURVEY 8d Config 5): most scalars byte-sized, so a few buckets of window 0 hold
     thousands of points and span many 256-entry segments of the sorted list (k_pip_segments / k_pip_fixup)."""

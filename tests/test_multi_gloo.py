@@ -110,6 +110,25 @@ def test_bench_two_ranks_strong_mode_on_one_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+def test_bench_sharded_msm_two_ranks_on_one_gpu():
+    """BASELINE.json configs[4] cut over ranks with real kernels: two rank processes on the one GPU (gloo for the gather),
+    each computes the partial sum of its half of a 2^18-point MSM, the two 64-byte partials are gathered and added; the result is
+    the one-rank MSM of the same points."""
+    import json
+    import subprocess
+    outs = []
+    for gpus in ("2", "1"):
+        env = dict(os.environ, SPP_BENCH_BACKEND="gloo", SPP_FORCE_DEVICE="0")
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", gpus, "--msm-shard-leg-only", "--msm-points", str(1 << 18)],
+                             env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        outs.append(json.loads(lines[0])["msm_g1_sharded"])
+    assert outs[0]["n_gpus"] == 2 and outs[1]["n_gpus"] == 1 and outs[0]["result_hex"] == outs[1]["result_hex"] and len(outs[0]["result_hex"]) == 128
+
+
+@pytest.mark.gpu
 def test_bench_single_rank_over_rccl(tmp_path):
     """RCCL itself (backend nccl) with one rank: rendezvous, the key broadcast, barriers and the reductions of bench.py run on
     the GPU through RCCL -- the multi-rank code path minus the peers, which a one-GPU box cannot supply."""
@@ -123,3 +142,48 @@ def test_bench_single_rank_over_rccl(tmp_path):
     assert out.returncode == 0, out.stderr[-3000:]
     j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert j["n_gpus"] == 1 and j["config"]["pk_bcast_backend"] == "nccl" and j["config"]["pk_bcast_ms"] > 0
+
+
+def _msm_worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, "shielded-pool-pinocchio-solana_amd"))
+    sys.path.insert(0, ROOT)
+    import random
+    import torch.distributed as dist
+    from spp.multi import msm_g1_sharded
+    from oracle import bn254 as B
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 37                                        # not a multiple of the world size
+    rng = random.Random(11)
+    pts = [B.g1_mul(B.G1_GEN, rng.randrange(1, B.R)) for _ in range(n)]
+    sc = [rng.randrange(B.R) for _ in range(n)]
+
+    def partial(lo, hi):                           # the CPU oracle stands in for Context.msm_g1_pippenger_bench_shard
+        acc = None
+        for i in range(lo, hi):
+            acc = B.g1_add(acc, B.g1_mul(pts[i], sc[i]))
+        return B.g1_to_bytes(acc)
+
+    def total(parts):
+        acc = None
+        for b in parts:
+            acc = B.g1_add(acc, B.g1_from_bytes(b))
+        return B.g1_to_bytes(acc)
+    got = msm_g1_sharded(dist, n, partial, total)
+    with open(os.path.join(out_dir, "m%d" % rank), "wb") as f:
+        f.write(got + partial(0, n))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_msm_gathers_the_partial_sums_world2():
+    """SURVEY 8e for BASELINE.json configs[4]: the points of ONE large MSM cut into contiguous shares, one partial sum per rank, one
+    all_gather of 64-byte points, the sum on every rank (spp/multi.py msm_g1_sharded; gloo here, RCCL on the GPU node): every rank ends
+    with the MSM of all points."""
+    d = tempfile.mkdtemp()
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_msm_worker, args=(2, port, d), nprocs=2, join=True)
+    for r in range(2):
+        blob = open(os.path.join(d, "m%d" % r), "rb").read()
+        assert len(blob) == 128 and blob[:64] == blob[64:]
