@@ -22,6 +22,10 @@
 #include <cstdlib>
 #include "f29.hpp"
 
+#ifndef SPP_G1_GATHER_PIPELINE
+#define SPP_G1_GATHER_PIPELINE 0   // experiment: the one-deep gather pipeline of the G2 walk for G1 as well
+#endif
+
 namespace spp {
 
 uint32_t msm_windows(uint32_t c) { return (254 + c - 1) / c; }
@@ -311,7 +315,7 @@ __global__ void __launch_bounds__(256) k_msm_flat(const Affine<F>* __restrict__ 
   const int16_t* __restrict__ dg = dig + ((size_t)rho * N) * Pp + p;
   MsmAcc<F> acc;
   acc.init();
-  if constexpr (sizeof(F) > sizeof(Fq)) {
+  if constexpr (sizeof(F) > sizeof(Fq) || SPP_G1_GATHER_PIPELINE) {
     // G2: one wave per SIMD (512 registers), nothing else to run while a gather is in flight -- the counters of the first
     // version showed 59 % VALU issue.  One-deep software pipeline: the entry of the next non-zero digit is requested BEFORE the
     // pending addition is computed.  A last pass over the loop body (flush) retires the pending addition, so that the ~40 KB
