@@ -239,8 +239,17 @@ struct Compiler {
     return true;
   }
 
+  // an output of a black box or of an unconstrained helper must be a witness nothing has defined yet: a blob that names an input
+  // or an already solved witness there would silently re-map it (spp_circuit_build_acir is a public entry point)
+  bool fresh(uint32_t w, uint32_t index) {
+    if (!known(w)) return true;
+    err = "opcode " + std::to_string(index) + ": output witness " + std::to_string(w) + " is already defined";
+    return false;
+  }
+
   bool msm(uint32_t lo, uint32_t hi, uint32_t ox, uint32_t oy, uint32_t oinf, uint32_t index) {
     if (!known(lo) || !known(hi)) { err = "opcode " + std::to_string(index) + ": MSM scalar unsolved"; return false; }
+    if (!fresh(ox, index) || !fresh(oy, index) || !fresh(oinf, index)) return false;
     // 256 consecutive bit wires: to_bits allocates its outputs back to back
     std::vector<LC> bits = b.to_bits(val(lo), 128);
     std::vector<LC> hbits = b.to_bits(val(hi), 128);
@@ -290,7 +299,7 @@ bool build_acir_circuit(const uint8_t* blob, size_t len, uint32_t circuit_id, Ci
         Expr e = read_expr(r);
         const uint32_t lg = r.u32(), oq = r.u32(), orr = r.u32();
         LC v;
-        ok = r.ok && lg % 8 == 0 && lg > 0 && lg < 256 && c.expr_value(e, &v);
+        ok = r.ok && lg % 8 == 0 && lg > 0 && lg < 256 && c.expr_value(e, &v) && c.fresh(oq, k) && c.fresh(orr, k) && oq != orr;
         if (ok) {
           std::vector<LC> limbs = c.b.limbs8_hint(v, 32);
           LC q, rem;
@@ -308,7 +317,7 @@ bool build_acir_circuit(const uint8_t* blob, size_t len, uint32_t circuit_id, Ci
         Expr e = read_expr(r);
         const uint32_t o = r.u32();
         LC v;
-        ok = r.ok && c.expr_value(e, &v);
+        ok = r.ok && c.expr_value(e, &v) && c.fresh(o, k);
         if (ok) c.wmap[o] = c.b.inv_hint(v);
         break;
       }
@@ -319,8 +328,11 @@ bool build_acir_circuit(const uint8_t* blob, size_t len, uint32_t circuit_id, Ci
         ok = r.ok && n > 0 && n <= 254 && c.expr_value(e, &v);
         if (ok) {
           std::vector<LC> bits = c.b.bits_hint(v, n);
-          for (uint32_t i = 0; i < n; i++) c.wmap[r.u32()] = bits[i];
-          ok = r.ok;
+          for (uint32_t i = 0; i < n && ok; i++) {
+            const uint32_t o = r.u32();
+            ok = r.ok && c.fresh(o, k);
+            if (ok) c.wmap[o] = bits[i];
+          }
         }
         break;
       }

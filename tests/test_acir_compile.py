@@ -157,6 +157,32 @@ def test_unsupported_programs_are_refused_with_a_reason(acir_circuit):
         acir.to_blob(prog)
 
 
+def test_lowering_refuses_an_output_that_is_already_defined(acir_circuit, tmp_path):
+    """a helper / black-box output must be a fresh witness.  A blob whose inverse helper writes to an INPUT witness (or
+    whose MultiScalarMul writes to an already solved one) is refused by spp_circuit_build_acir instead of silently re-mapping it."""
+    import copy
+    import ctypes
+    from spp import acir
+    from spp.lib import load_library, last_error
+    prog = copy.copy(acir_circuit["prog"])
+    prog.main = copy.copy(prog.main)
+    prog.main.opcodes = list(prog.main.opcodes)
+    L = load_library()
+    out = str(tmp_path / "bad.sppc")
+    n = ctypes.c_uint32(0)
+    k = next(i for i, op in enumerate(prog.main.opcodes) if op[0] == "BrilligCall" and prog.brillig_kind(i, op[1], op[2], op[3]) == "inverse")
+    op = prog.main.opcodes[k]
+    prog.main.opcodes[k] = (op[0], op[1], op[2], [("simple", 3)], op[4])                    # witness 3 = the public `amount`
+    blob = acir.to_blob(prog)
+    assert L.spp_circuit_build_acir(blob, len(blob), 1, out.encode(), ctypes.byref(n)) != 0 and "already defined" in last_error()
+    prog.main.opcodes[k] = op
+    k = next(i for i, op_ in enumerate(prog.main.opcodes) if op_[0] == "MultiScalarMul")
+    op = prog.main.opcodes[k]
+    prog.main.opcodes[k] = (op[0], op[1], op[2], op[3], (op[4][0], 5, op[4][2]))              # y output onto the secret key's witness
+    blob = acir.to_blob(prog)
+    assert L.spp_circuit_build_acir(blob, len(blob), 1, out.encode(), ctypes.byref(n)) != 0 and "already defined" in last_error()
+
+
 @pytest.mark.gpu
 def test_gpu_proves_the_reference_acir_circuit(acir_circuit, withdraw_kat, tmp_path):
     """The reference's compiled circuit on the GPU: setup bytes == oracle setup, 64 distinct notes proved, a sample byte-identical
