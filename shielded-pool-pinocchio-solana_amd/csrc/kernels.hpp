@@ -206,6 +206,10 @@ struct MsmFoldSets {
 template <class F>
 void launch_msm_reduce_multi(hipStream_t st, MsmFoldSets<F> fs, uint32_t nsets, uint32_t P);
 
+// the H bases of a proving key in the evaluation basis on the coset (kernels_msm.hip): out[bitrev(i)] = Z'_i
+void launch_g1_eval_basis(hipStream_t st, const G1Affine* pts, uint32_t n_pts, uint32_t logn, const Fr* scale, const Fr* tw_inv, G1XYZZ* work,
+                          G1Affine* out);
+
 // ---- general-base Pippenger (kernels_pippenger.hip) ----
 size_t pippenger_workspace_bytes(uint32_t n);
 size_t pippenger_workspace_bytes_g2(uint32_t n);

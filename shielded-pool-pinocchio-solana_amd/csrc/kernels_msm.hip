@@ -560,6 +560,64 @@ template void launch_msm_reduce<Fq>(hipStream_t, XYZZ<Fq>*, XYZZ<Fq>*, uint32_t,
 template void launch_msm_reduce<Fq2>(hipStream_t, XYZZ<Fq2>*, XYZZ<Fq2>*, uint32_t, const MsmPlan&, uint32_t, bool);
 
 // ----------------------------------------------------------------------------------------------------
+// The H bases in the evaluation basis (load time).  gnark's computeH ends with an inverse coset transform that turns the
+// values of h on the coset g*H into coefficients, because pk.G1.Z is a coefficient basis (Z_j = [tau^j t(tau) / delta]).
+// sum_j h_j Z_j = sum_i h(g w^i) Z'_i  with  Z'_i = sum_j (g^-j / n) w^(-ij) Z_j : a DFT "in the exponent" of the n - 1 points
+// (scaled, padded with the point at infinity), done ONCE when the circuit is loaded -- n + (n/2) log2 n scalar multiplications,
+// ~60 ms for n = 2^15 -- and every proof saves its seventh transform (the scalars of the Z walk are the values the pointwise
+// kernel leaves, natural order).  The group element is the same, so are the proof bytes.
+// ----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ XYZZ<Fq> g1_scalar_mul(const XYZZ<Fq>& pt, const Fr& k) {
+  uint32_t c[8];
+  k.to_canonical(c);
+  XYZZ<Fq> acc = XYZZ<Fq>::infinity();
+  if (pt.is_inf()) return acc;
+#pragma unroll 1
+  for (int w = 7; w >= 0; w--) {
+    const uint32_t word = w == 0 ? c[0] : w == 1 ? c[1] : w == 2 ? c[2] : w == 3 ? c[3] : w == 4 ? c[4] : w == 5 ? c[5] : w == 6 ? c[6] : c[7];
+#pragma unroll 1
+    for (int bit = 31; bit >= 0; bit--) {
+      acc.dbl_inplace();
+      if ((word >> bit) & 1) acc.add(pt);
+    }
+  }
+  return acc;
+}
+// x[j] = scale[j] * affine[j] (j < n_pts), infinity above
+__global__ void __launch_bounds__(64) k_g1_dft_load(const G1Affine* __restrict__ pts, uint32_t n_pts, const Fr* __restrict__ scale,
+                                                    G1XYZZ* __restrict__ x, uint32_t n) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  x[j] = j < n_pts ? g1_scalar_mul(G1XYZZ::from_affine(pts[j]), scale[j]) : G1XYZZ::infinity();
+}
+// one decimation-in-frequency stage (natural in, bit-reversed out after log2 n stages): block length len, twiddles tw[k] = w^k
+__global__ void __launch_bounds__(64) k_g1_dft_stage(G1XYZZ* __restrict__ x, uint32_t n, uint32_t len, const Fr* __restrict__ tw) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n / 2) return;
+  const uint32_t half = len / 2, j = g % half, b = (g / half) * len;
+  G1XYZZ u = x[b + j], v = x[b + j + half];
+  G1XYZZ d = u;
+  d.add(v.neg());
+  u.add(v);
+  x[b + j] = u;
+  const uint32_t e = j * (n / len);
+  x[b + j + half] = e ? g1_scalar_mul(d, tw[e]) : d;
+}
+__global__ void __launch_bounds__(64) k_g1_to_affine(const G1XYZZ* __restrict__ x, G1Affine* __restrict__ out, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = x[i].to_affine();
+}
+// out[bitrev(i)] = Z'_i for i < n = 2^logn (the caller undoes the bit reversal); scale[j] = g^-j / n, tw_inv[k] = w^-k (k < n/2)
+void launch_g1_eval_basis(hipStream_t st, const G1Affine* pts, uint32_t n_pts, uint32_t logn, const Fr* scale, const Fr* tw_inv, G1XYZZ* work,
+                          G1Affine* out) {
+  const uint32_t n = 1u << logn;
+  hipLaunchKernelGGL(k_g1_dft_load, dim3((n + 63) / 64), dim3(64), 0, st, pts, n_pts, scale, work, n);
+  for (uint32_t len = n; len >= 2; len >>= 1)
+    hipLaunchKernelGGL(k_g1_dft_stage, dim3((n / 2 + 63) / 64), dim3(64), 0, st, work, n, len, tw_inv);
+  hipLaunchKernelGGL(k_g1_to_affine, dim3((n + 63) / 64), dim3(64), 0, st, work, out, n);
+}
+
+// ----------------------------------------------------------------------------------------------------
 // setup: out[i] = scalars[i] * G using the window table of the single base G
 // ----------------------------------------------------------------------------------------------------
 template <class F>

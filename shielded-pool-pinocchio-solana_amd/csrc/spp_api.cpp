@@ -90,6 +90,7 @@ struct spp_circuit {
   uint32_t c_bits = 10, n = 0, logn = 0;
   uint32_t max_batch_div = SOLVE_SCRATCH_MIN_ROWS;
   DevCoop coop{};
+  bool z_eval_basis = false;      // the Z set holds the H bases in the evaluation basis on the coset: no seventh transform
   bool generic_solver = false;    // the program is the solver of a decoded gnark system (OP_SOLVE_ROW ...): ~12 K dependent row solves per
                                   // proof on one lane -- a batch's solver phase outlasts the rest of it, so three batches take turns
   bool no_coop = false;           // SPP_NO_COOP=1 (diagnostic): always the one-lane-per-proof solver
@@ -1220,15 +1221,49 @@ static int load_circuit_impl(spp_ctx* ctx, const char* circuit_path, const char*
     if ((e = make_set(c, &c->K, w, p, false, cw[2], flat[2]))) return e;
   }
   {
-    // h comes out of the last DIF pass in bit-reversed order: row `pos` holds h_{bitrev(pos)}
     if (pk.Z.size() != (size_t)c->n - 1) return fail(SPP_ERR_FORMAT, "Z section has %zu points, expected %u", pk.Z.size(), c->n - 1);
     std::vector<uint32_t> w;
     std::vector<G1Affine> p;
-    for (uint32_t pos = 0; pos < c->n; pos++) {
-      uint32_t i = bitrev(pos, c->logn);
-      if (i == c->n - 1) continue;
-      w.push_back(pos);
-      p.push_back(pk.Z[i]);
+    // Default: the H bases are moved to the evaluation basis on the coset once, here (kernels_msm.hip, launch_g1_eval_basis), and
+    // the scalars of the Z walk are the values the pointwise kernel leaves in natural order -- a proof then needs six transforms
+    // instead of gnark's seven.  SPP_Z_COEFF=1 (comparison): the coefficient basis of the proving key and the seventh transform.
+    c->z_eval_basis = getenv("SPP_Z_COEFF") == nullptr;
+    if (c->z_eval_basis) {
+      const uint32_t n = c->n;
+      Fr g = Fr::from_u64(5), gi = g.inv(), x = Fr::from_u64(n).inv();
+      std::vector<Fr> scale(n);
+      for (uint32_t j = 0; j < n; j++) {
+        scale[j] = x;
+        x = x * gi;
+      }
+      DevBuf d_pts, d_scale, d_work, d_out;
+      HIP_TRY(d_pts.alloc(pk.Z.size() * sizeof(G1Affine)));
+      HIP_TRY(d_scale.alloc((size_t)n * sizeof(Fr)));
+      HIP_TRY(d_work.alloc((size_t)n * sizeof(G1XYZZ)));
+      HIP_TRY(d_out.alloc((size_t)n * sizeof(G1Affine)));
+      hipStream_t st = ctx->stream;
+      HIP_TRY(hipMemcpyAsync(d_pts.p, pk.Z.data(), pk.Z.size() * sizeof(G1Affine), hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(d_scale.p, scale.data(), (size_t)n * sizeof(Fr), hipMemcpyHostToDevice, st));
+      launch_g1_eval_basis(st, d_pts.as<G1Affine>(), (uint32_t)pk.Z.size(), c->logn, d_scale.as<Fr>(), c->tw_inv, d_work.as<G1XYZZ>(),
+                           d_out.as<G1Affine>());
+      std::vector<G1Affine> br(n);
+      HIP_TRY(hipMemcpyAsync(br.data(), d_out.p, (size_t)n * sizeof(G1Affine), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      HIP_TRY(hipGetLastError());
+      p.resize(n);
+      w.resize(n);
+      for (uint32_t pos = 0; pos < n; pos++) {
+        p[bitrev(pos, c->logn)] = br[pos];     // the DIF stages leave Z'_i at position bitrev(i)
+        w[pos] = pos;                          // row i of the a-slot holds h(g w^i)
+      }
+    } else {
+      // h comes out of the last DIF pass in bit-reversed order: row `pos` holds h_{bitrev(pos)}
+      for (uint32_t pos = 0; pos < c->n; pos++) {
+        uint32_t i = bitrev(pos, c->logn);
+        if (i == c->n - 1) continue;
+        w.push_back(pos);
+        p.push_back(pk.Z[i]);
+      }
     }
     if ((e = make_set(c, &c->Z, w, p, true, cw[3], flat[3]))) return e;
   }
@@ -1495,7 +1530,7 @@ static int prove_on_device(spp_circuit* c, Workspace& w, uint32_t P, const uint8
   launch_ntt(st, w.abc, c->logn, P, c->tw_inv, true, 3, bs, c->coset_br);
   launch_ntt(st, w.abc, c->logn, P, c->tw_fwd, false, 3, bs);
   launch_qap_pointwise(st, w.abc, n, P, c->zinv);
-  launch_ntt(st, w.abc, c->logn, P, c->tw_inv, true, 1, bs, c->coset_inv_br);
+  if (!c->z_eval_basis) launch_ntt(st, w.abc, c->logn, P, c->tw_inv, true, 1, bs, c->coset_inv_br);   // else: the Z bases are in the evaluation basis
   hipEventRecord(w.ev[3], st);
   // 4. MSMs
   {
