@@ -162,6 +162,7 @@ void launch_ntt(hipStream_t st, Fr* data, uint32_t logn, uint32_t P, const Fr* t
                 const Fr* post = nullptr);
 void launch_scale_rows(hipStream_t st, Fr* data, const Fr* table, uint32_t n, uint32_t P, uint32_t nbatch, size_t batch_stride);
 void launch_qap_pointwise(hipStream_t st, Fr* abc, uint32_t n, uint32_t P, Fr zinv);
+void launch_qap_product(hipStream_t st, Fr* abc, uint32_t n, uint32_t P);   // a <- a * b
 
 // ---- MSM with precomputed window tables (kernels_msm.hip) ----
 // A base carries Wt table rows of 2^(c-1) affine multiples; row m = multiples of 2^(c*R*m) * Base, R = ceil(W / Wt) window passes
@@ -209,6 +210,10 @@ void launch_msm_reduce_multi(hipStream_t st, MsmFoldSets<F> fs, uint32_t nsets, 
 // the H bases of a proving key in the evaluation basis on the coset (kernels_msm.hip): out[bitrev(i)] = Z'_i
 void launch_g1_eval_basis(hipStream_t st, const G1Affine* pts, uint32_t n_pts, uint32_t logn, const Fr* scale, const Fr* tw_inv, G1XYZZ* work,
                           G1Affine* out);
+
+// out[s] = sum over t in [seg[s], seg[s+1]) of coeff[t] * base[row[t]]  (work: nterms points)
+void launch_g1_column_sums(hipStream_t st, const G1Affine* base, const uint32_t* row, const Fr* coeff, uint32_t nterms, const uint32_t* seg,
+                           uint32_t nseg, G1XYZZ* work, G1Affine* out);
 
 // ---- general-base Pippenger (kernels_pippenger.hip) ----
 size_t pippenger_workspace_bytes(uint32_t n);

@@ -607,6 +607,31 @@ __global__ void __launch_bounds__(64) k_g1_to_affine(const G1XYZZ* __restrict__ 
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = x[i].to_affine();
 }
+// term t: coeff[t] * base[row[t]]; then segment s = sum of terms [seg[s], seg[s+1]) as an affine point (the column sums
+// X_wire = sum_i C[i][wire] * W_i of the product form of computeH, spp_api.cpp)
+__global__ void __launch_bounds__(64) k_g1_terms(const G1Affine* __restrict__ base, const uint32_t* __restrict__ row, const Fr* __restrict__ coeff,
+                                                 uint32_t nterms, G1XYZZ* __restrict__ out) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nterms) return;
+  const G1XYZZ p = G1XYZZ::from_affine(base[row[t]]);
+  const Fr c = coeff[t];
+  if (c == Fr::one()) out[t] = p;
+  else if (c == Fr::one().neg()) out[t] = p.neg();
+  else out[t] = g1_scalar_mul(p, c);
+}
+__global__ void __launch_bounds__(64) k_g1_segsum(const G1XYZZ* __restrict__ terms, const uint32_t* __restrict__ seg, uint32_t nseg,
+                                                  G1Affine* __restrict__ out) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nseg) return;
+  G1XYZZ acc = G1XYZZ::infinity();
+  for (uint32_t t = seg[s]; t < seg[s + 1]; t++) acc.add(terms[t]);
+  out[s] = acc.to_affine();
+}
+void launch_g1_column_sums(hipStream_t st, const G1Affine* base, const uint32_t* row, const Fr* coeff, uint32_t nterms, const uint32_t* seg,
+                           uint32_t nseg, G1XYZZ* work, G1Affine* out) {
+  if (nterms) hipLaunchKernelGGL(k_g1_terms, dim3((nterms + 63) / 64), dim3(64), 0, st, base, row, coeff, nterms, work);
+  if (nseg) hipLaunchKernelGGL(k_g1_segsum, dim3((nseg + 63) / 64), dim3(64), 0, st, work, seg, nseg, out);
+}
 // out[bitrev(i)] = Z'_i for i < n = 2^logn (the caller undoes the bit reversal); scale[j] = g^-j / n, tw_inv[k] = w^-k (k < n/2)
 void launch_g1_eval_basis(hipStream_t st, const G1Affine* pts, uint32_t n_pts, uint32_t logn, const Fr* scale, const Fr* tw_inv, G1XYZZ* work,
                           G1Affine* out) {

@@ -183,6 +183,18 @@ __global__ void __launch_bounds__(256) k_qap_pointwise(Fr* __restrict__ abc, uin
   for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (uint64_t)gridDim.x * blockDim.x)
     a[g] = (a[g] * b[g] - c[g]) * zinv;
 }
+// a <- a * b over [n][P]: the values of A(X) B(X) on the coset zeta * H (product form of computeH, spp_api.cpp)
+__global__ void __launch_bounds__(256) k_qap_product(Fr* __restrict__ abc, uint64_t total) {
+  Fr* a = abc;
+  const Fr* b = abc + total;
+  for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (uint64_t)gridDim.x * blockDim.x) a[g] = a[g] * b[g];
+}
+void launch_qap_product(hipStream_t st, Fr* abc, uint32_t n, uint32_t P) {
+  uint64_t total = (uint64_t)n * P;
+  uint32_t blocks = (uint32_t)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_qap_product, dim3(blocks), dim3(256), 0, st, abc, total);
+}
 void launch_qap_pointwise(hipStream_t st, Fr* abc, uint32_t n, uint32_t P, Fr zinv) {
   uint64_t total = (uint64_t)n * P;
   uint32_t blocks = (uint32_t)((total + 255) / 256);

@@ -90,7 +90,14 @@ struct spp_circuit {
   uint32_t c_bits = 10, n = 0, logn = 0;
   uint32_t max_batch_div = SOLVE_SCRATCH_MIN_ROWS;
   DevCoop coop{};
-  bool z_eval_basis = false;      // the Z set holds the H bases in the evaluation basis on the coset: no seventh transform
+  // How h = (A B - C) / Z reaches Krs (SPP_H_MODE, default 2):
+  //   0  gnark's computeH: 3 inverse + 3 coset-forward + 1 coset-inverse transform, h coefficients against pk.G1.Z
+  //   1  the H bases moved to the evaluation basis on the coset g*H at load: six transforms
+  //   2  product form: h is the HIGH HALF of the product polynomial A(X) B(X) (A B = h (X^n - 1) + C with deg C < n), whose
+  //      coefficients are a linear functional of its values on the 2n-th roots of unity H u zeta*H.  On H the values are a_i b_i =
+  //      c_i = <C_i, w> -- linear in the witness, folded into per-wire bases at load; on zeta*H they need the transforms of A and
+  //      B only: FOUR transforms, no transform of C, the same group element (spp_load_circuit, "product form")
+  int h_mode = 2;
   bool generic_solver = false;    // the program is the solver of a decoded gnark system (OP_SOLVE_ROW ...): ~12 K dependent row solves per
                                   // proof on one lane -- a batch's solver phase outlasts the rest of it, so three batches take turns
   bool no_coop = false;           // SPP_NO_COOP=1 (diagnostic): always the one-lane-per-proof solver
@@ -1171,7 +1178,14 @@ static int load_circuit_impl(spp_ctx* ctx, const char* circuit_path, const char*
       a = a * w;
       b = b * wi;
     }
-    Fr g = Fr::from_u64(5), gi = g.inv(), ninv = Fr::from_u64(n).inv();
+    {
+      const char* hm = getenv("SPP_H_MODE");
+      c->h_mode = hm ? atoi(hm) : (getenv("SPP_Z_COEFF") ? 0 : 2);
+      if (c->h_mode < 0 || c->h_mode > 2) c->h_mode = 2;
+    }
+    // the coset: gnark's multiplicative generator 5, or -- product form -- zeta, the primitive 2n-th root of unity with
+    // zeta^2 = w, so that H u zeta*H are the 2n-th roots of unity
+    Fr g = c->h_mode == 2 ? fr_root_of_unity(logn + 1) : Fr::from_u64(5), gi = g.inv(), ninv = Fr::from_u64(n).inv();
     std::vector<Fr> gp(n), gip(n);
     Fr x = ninv, y = ninv;
     for (uint32_t i = 0; i < n; i++) {
@@ -1214,34 +1228,20 @@ static int load_circuit_impl(spp_ctx* ctx, const char* circuit_path, const char*
     w.push_back(c->row_s); p.push_back(pk.delta2);
     if ((e = make_set(c, &c->B2, w, p, false, cw[6], flat[6]))) return e;
   }
-  {
-    std::vector<uint32_t> w = pk.K_w;
-    std::vector<G1Affine> p = pk.K;
-    w.push_back(c->row_rs); p.push_back(pk.delta1.neg());
-    if ((e = make_set(c, &c->K, w, p, false, cw[2], flat[2]))) return e;
-  }
+  // ---- the H bases (and, in the product form, the per-wire column sums that join the K set) ----
+  std::vector<uint32_t> z_w, xk_w;
+  std::vector<G1Affine> z_p, xk_p;
   {
     if (pk.Z.size() != (size_t)c->n - 1) return fail(SPP_ERR_FORMAT, "Z section has %zu points, expected %u", pk.Z.size(), c->n - 1);
-    std::vector<uint32_t> w;
-    std::vector<G1Affine> p;
-    // Default: the H bases are moved to the evaluation basis on the coset once, here (kernels_msm.hip, launch_g1_eval_basis), and
-    // the scalars of the Z walk are the values the pointwise kernel leaves in natural order -- a proof then needs six transforms
-    // instead of gnark's seven.  SPP_Z_COEFF=1 (comparison): the coefficient basis of the proving key and the seventh transform.
-    c->z_eval_basis = getenv("SPP_Z_COEFF") == nullptr;
-    if (c->z_eval_basis) {
-      const uint32_t n = c->n;
-      Fr g = Fr::from_u64(5), gi = g.inv(), x = Fr::from_u64(n).inv();
-      std::vector<Fr> scale(n);
-      for (uint32_t j = 0; j < n; j++) {
-        scale[j] = x;
-        x = x * gi;
-      }
+    const uint32_t n = c->n;
+    hipStream_t st = ctx->stream;
+    // out[i] = sum_j scale[j] w^(-ij) Z_j, natural order (group DFT on the device, kernels_msm.hip)
+    auto eval_basis = [&](const std::vector<Fr>& scale, std::vector<G1Affine>& out) -> int {
       DevBuf d_pts, d_scale, d_work, d_out;
       HIP_TRY(d_pts.alloc(pk.Z.size() * sizeof(G1Affine)));
       HIP_TRY(d_scale.alloc((size_t)n * sizeof(Fr)));
       HIP_TRY(d_work.alloc((size_t)n * sizeof(G1XYZZ)));
       HIP_TRY(d_out.alloc((size_t)n * sizeof(G1Affine)));
-      hipStream_t st = ctx->stream;
       HIP_TRY(hipMemcpyAsync(d_pts.p, pk.Z.data(), pk.Z.size() * sizeof(G1Affine), hipMemcpyHostToDevice, st));
       HIP_TRY(hipMemcpyAsync(d_scale.p, scale.data(), (size_t)n * sizeof(Fr), hipMemcpyHostToDevice, st));
       launch_g1_eval_basis(st, d_pts.as<G1Affine>(), (uint32_t)pk.Z.size(), c->logn, d_scale.as<Fr>(), c->tw_inv, d_work.as<G1XYZZ>(),
@@ -1250,23 +1250,98 @@ static int load_circuit_impl(spp_ctx* ctx, const char* circuit_path, const char*
       HIP_TRY(hipMemcpyAsync(br.data(), d_out.p, (size_t)n * sizeof(G1Affine), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
       HIP_TRY(hipGetLastError());
-      p.resize(n);
-      w.resize(n);
-      for (uint32_t pos = 0; pos < n; pos++) {
-        p[bitrev(pos, c->logn)] = br[pos];     // the DIF stages leave Z'_i at position bitrev(i)
-        w[pos] = pos;                          // row i of the a-slot holds h(g w^i)
-      }
-    } else {
+      out.resize(n);
+      for (uint32_t pos = 0; pos < n; pos++) out[bitrev(pos, c->logn)] = br[pos];     // the DIF stages leave element i at bitrev(i)
+      return 0;
+    };
+    if (c->h_mode == 0) {
       // h comes out of the last DIF pass in bit-reversed order: row `pos` holds h_{bitrev(pos)}
-      for (uint32_t pos = 0; pos < c->n; pos++) {
+      for (uint32_t pos = 0; pos < n; pos++) {
         uint32_t i = bitrev(pos, c->logn);
-        if (i == c->n - 1) continue;
-        w.push_back(pos);
-        p.push_back(pk.Z[i]);
+        if (i == n - 1) continue;
+        z_w.push_back(pos);
+        z_p.push_back(pk.Z[i]);
+      }
+    } else if (c->h_mode == 1) {
+      // sum_j h_j Z_j = sum_i h(g w^i) Z'_i with Z'_i = sum_j (g^-j / n) w^(-ij) Z_j; row i of the a-slot holds h(g w^i)
+      Fr gi = Fr::from_u64(5).inv(), x = Fr::from_u64(n).inv();
+      std::vector<Fr> scale(n);
+      for (uint32_t j = 0; j < n; j++) { scale[j] = x; x = x * gi; }
+      if ((e = eval_basis(scale, z_p))) return e;
+      for (uint32_t i = 0; i < n; i++) z_w.push_back(i);
+    } else {
+      // Product form.  P = A B has degree <= 2n - 2 and h_j = P_{n+j}; over D = the 2n-th roots of unity P_k = (1/2n) sum_{x in D}
+      // P(x) x^-k, hence  sum_j h_j Z_j = sum_{x in D} P(x) W_x  with  W_x = (1/2n) sum_j x^-(n+j) Z_j:
+      //   x = w^i        (x^-n = 1):   W_i  =  (1/2n) sum_j w^(-ij) Z_j,              P(x) = a_i b_i = c_i = <C_i, witness>
+      //   x = zeta w^i   (x^-n = -1):  W'_i = -(1/2n) sum_j zeta^-j w^(-ij) Z_j,      P(x) = A(x) B(x) from two coset transforms
+      // The first sum is linear in the witness: sum_i c_i W_i = sum_wire w_wire X_wire, X_wire = sum_i C[i][wire] W_i -- a point per
+      // wire, computed here once and added to the wire's base in the K set (wires without one -- public, committed, the
+      // challenge -- join the set with X_wire alone: the sum is part of Krs whatever the wire's class).
+      const Fr inv2n = Fr::from_u64(2 * (uint64_t)n).inv();
+      std::vector<Fr> scale(n, inv2n);
+      std::vector<G1Affine> WH;
+      if ((e = eval_basis(scale, WH))) return e;
+      Fr zi = fr_root_of_unity(c->logn + 1).inv(), x = inv2n.neg();
+      for (uint32_t j = 0; j < n; j++) { scale[j] = x; x = x * zi; }
+      if ((e = eval_basis(scale, z_p))) return e;
+      for (uint32_t i = 0; i < n; i++) z_w.push_back(i);
+      // column sums of C against W
+      struct Tm { uint32_t wire, row; Fr cf; };
+      std::vector<Tm> tms;
+      for (uint32_t k = 0; k < circ.n_constraints; k++)
+        for (uint32_t t = circ.C.rowptr[k]; t < circ.C.rowptr[k + 1]; t++) tms.push_back({circ.C.terms[t].wire, k, circ.coeffs[circ.C.terms[t].coeff]});
+      std::stable_sort(tms.begin(), tms.end(), [](const Tm& a, const Tm& b) { return a.wire < b.wire; });
+      std::vector<uint32_t> rows(tms.size()), seg{0};
+      std::vector<Fr> cfs(tms.size());
+      for (size_t t = 0; t < tms.size(); t++) {
+        rows[t] = tms[t].row;
+        cfs[t] = tms[t].cf;
+        if (t + 1 == tms.size() || tms[t + 1].wire != tms[t].wire) {
+          xk_w.push_back(tms[t].wire);
+          seg.push_back((uint32_t)t + 1);
+        }
+      }
+      if (!tms.empty()) {
+        DevBuf d_base, d_rows, d_cfs, d_seg, d_work, d_out;
+        HIP_TRY(d_base.alloc((size_t)n * sizeof(G1Affine)));
+        HIP_TRY(d_rows.alloc(rows.size() * 4));
+        HIP_TRY(d_cfs.alloc(cfs.size() * sizeof(Fr)));
+        HIP_TRY(d_seg.alloc(seg.size() * 4));
+        HIP_TRY(d_work.alloc(tms.size() * sizeof(G1XYZZ)));
+        HIP_TRY(d_out.alloc(xk_w.size() * sizeof(G1Affine)));
+        HIP_TRY(hipMemcpyAsync(d_base.p, WH.data(), (size_t)n * sizeof(G1Affine), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_rows.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_cfs.p, cfs.data(), cfs.size() * sizeof(Fr), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_seg.p, seg.data(), seg.size() * 4, hipMemcpyHostToDevice, st));
+        launch_g1_column_sums(st, d_base.as<G1Affine>(), d_rows.as<uint32_t>(), d_cfs.as<Fr>(), (uint32_t)tms.size(), d_seg.as<uint32_t>(),
+                              (uint32_t)xk_w.size(), d_work.as<G1XYZZ>(), d_out.as<G1Affine>());
+        xk_p.resize(xk_w.size());
+        HIP_TRY(hipMemcpyAsync(xk_p.data(), d_out.p, xk_p.size() * sizeof(G1Affine), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipGetLastError());
       }
     }
-    if ((e = make_set(c, &c->Z, w, p, true, cw[3], flat[3]))) return e;
   }
+  {
+    std::vector<uint32_t> w = pk.K_w;
+    std::vector<G1Affine> p = pk.K;
+    if (!xk_w.empty()) {   // product form: K_wire + X_wire (one pass over a wire -> position map; merge_point is linear per call)
+      std::vector<int32_t> at(circ.n_wires + 3, -1);
+      for (size_t i = 0; i < w.size(); i++) at[w[i]] = (int32_t)i;
+      for (size_t i = 0; i < xk_w.size(); i++) {
+        if (xk_p[i].is_inf()) continue;
+        if (at[xk_w[i]] >= 0) p[at[xk_w[i]]] = host_add(p[at[xk_w[i]]], xk_p[i]);
+        else {
+          at[xk_w[i]] = (int32_t)w.size();
+          w.push_back(xk_w[i]);
+          p.push_back(xk_p[i]);
+        }
+      }
+    }
+    w.push_back(c->row_rs); p.push_back(pk.delta1.neg());
+    if ((e = make_set(c, &c->K, w, p, false, cw[2], flat[2]))) return e;
+  }
+  if ((e = make_set(c, &c->Z, z_w, z_p, true, cw[3], flat[3]))) return e;
   if ((e = make_set(c, &c->CB, pk.CB_w, pk.CB, false, cw[4], false))) return e;
   if ((e = make_set(c, &c->CS, pk.CS_w, pk.CS, false, cw[5], false))) return e;
   if ((e = build_pending(c))) return e;
@@ -1527,10 +1602,12 @@ static int prove_on_device(spp_circuit* c, Workspace& w, uint32_t P, const uint8
   // 3. h = (a*b - c)/Z  (coefficients land bit-reversed in the a-slot of abc)
   const size_t bs = (size_t)n * P;
   // the coset shifts ride on the stores of the inverse transforms' last pass (no separate pass over the arrays)
-  launch_ntt(st, w.abc, c->logn, P, c->tw_inv, true, 3, bs, c->coset_br);
-  launch_ntt(st, w.abc, c->logn, P, c->tw_fwd, false, 3, bs);
-  launch_qap_pointwise(st, w.abc, n, P, c->zinv);
-  if (!c->z_eval_basis) launch_ntt(st, w.abc, c->logn, P, c->tw_inv, true, 1, bs, c->coset_inv_br);   // else: the Z bases are in the evaluation basis
+  const uint32_t nt = c->h_mode == 2 ? 2 : 3;      // product form: A and B only
+  launch_ntt(st, w.abc, c->logn, P, c->tw_inv, true, nt, bs, c->coset_br);
+  launch_ntt(st, w.abc, c->logn, P, c->tw_fwd, false, nt, bs);
+  if (c->h_mode == 2) launch_qap_product(st, w.abc, n, P);
+  else launch_qap_pointwise(st, w.abc, n, P, c->zinv);
+  if (c->h_mode == 0) launch_ntt(st, w.abc, c->logn, P, c->tw_inv, true, 1, bs, c->coset_inv_br);   // else: the Z bases are in the evaluation basis
   hipEventRecord(w.ev[3], st);
   // 4. MSMs
   {
