@@ -610,6 +610,32 @@ def test_audit_proof_bytes_match_oracle_and_verify(ctx, audit_artifacts, rlwe_pk
         h.close()
 
 
+def test_compute_h_forms_agree_with_the_oracle(ctx, withdraw_artifacts, audit_artifacts, withdraw_kat, rlwe_pk, monkeypatch):
+    """computeH three ways ("computeH in product form"): gnark's seven transforms (SPP_H_MODE=0: h coefficients
+    against pk.G1.Z, groth16/bn254/prove.go computeH), six (H bases moved to the evaluation basis on 5*H) and four (the default: h as
+    the high half of A*B, the H half of its values folded into the K bases).  All three must emit the bytes of the C oracle, which
+    keeps gnark's form: Krs is one group element however it is summed."""
+    from oracle import native
+    wrows = _withdraw_variants(withdraw_kat, 5)
+    arows = _audit_rows(rlwe_pk, 3)
+    for art, rows in ((withdraw_artifacts, wrows), (audit_artifacts, arows)):
+        rs = [(101 + 7 * i, 33 + i) for i in range(len(rows))]
+        orc = native.Prover(art["sppc"], art["pk"])
+        want = [orc.prove(rows[i], *rs[i]) for i in range(len(rows))]
+        assert all(w[0] == 0 for w in want)
+        for mode in ("0", "1", "2"):
+            monkeypatch.setenv("SPP_H_MODE", mode)
+            h = ctx.load_circuit(art["sppc"], art["pk"], 6)
+            try:
+                proofs, pws, status = h.prove_batch(rows, rs)
+            finally:
+                h.close()
+            assert status == [0] * len(rows), (mode, status)
+            for i in range(len(rows)):
+                assert proofs[i] == want[i][1] and pws[i] == want[i][2], (mode, i)
+    monkeypatch.delenv("SPP_H_MODE")
+
+
 # ---------------------------------------------------------------------------------------------- witness-input kernels
 def test_rlwe_witness_matches_reference_fixtures(ctx, rlwe_pk, rlwe_vectors):
     """The reference's own values (tests/golden/rlwe_vectors.json, produced by importing scripts/generate_audit.py)."""
