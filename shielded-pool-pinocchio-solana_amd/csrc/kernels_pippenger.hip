@@ -6,14 +6,22 @@
 //                     as int16 [16][n] -- the later passes read 2 B per point and window instead of a 32 B scalar
 //   1. k_pip_count    one 1024-lane workgroup per (window, tile of 2^20 points): histogram over the 2^15 buckets in LDS
 //                     (128 KB of the CU's 160 KB; ds_add_u32), written out once per tile -- no global atomics
-//   2. k_pip_totals   lane per (window, bucket): bucket totals + exclusive prefix over the tiles;  k_pip_scan: exclusive
-//                     prefix over the buckets of a window                                                       (LDS scan)
-//   3. k_pip_scatter  same workgroups as 1: LDS cursors start at offs[bucket] + prefix[tile][bucket]; a point's slot comes
-//                     from an LDS atomic, (index | sign) goes to its bucket's segment -- again no global atomics
+//   2. k_pip_totals   lane per (window, bucket): bucket totals;  k_pip_scan: exclusive prefix over the buckets of a window
+//   3. the bucket sort, TWO LEVELS (round 3).  One pass with 2^15 destinations wrote every 4-byte entry
+//      to a line of its own (6.8 GB of HBM writes for 1.07 GB of payload, 6.8 ms): a 2^20-point tile puts 32 entries into each
+//      bucket, spread over the whole pass.  Now each pass has few destinations per workgroup, all written between two barriers:
+//      k_pip_part1    workgroup per (window, 16 K points): ranks within the 256 COARSE bins (bucket >> 7) from LDS atomics,
+//                     one global atomic per bin and workgroup claims the run, then (index | sign) and the 7 fine key bits go
+//                     out in runs of ~64 entries (256 B + 64 B) that the L2 completes before it writes them back
+//      k_pip_part2    workgroup per (window, 16 K entries of that list): the same by bucket inside the coarse bins the
+//                     piece touches (normally one or two: <= 256 counters; a skewed window may put many small bins into
+//                     one piece, the counter array covers all 2^15 buckets), runs of ~64 entries into the final list
 //   4. k_pip_segments lane per 256-entry segment of a window's sorted list: gathers its points (64 B each) and folds them
 //                     with mixed additions per bucket; k_pip_fixup joins the buckets that span segments
-//   5. k_pip_chunks   lane per 64-bucket chunk: running sums  S = sum B_b,  T = sum (b_local+1) B_b
-//   6. k_pip_windows  64-lane block per window:  sum_chunks (T_c + 64 c S_c)  with an LDS tree
+//   5. k_pip_chunks   lane per 16-bucket chunk: running sums  S = sum B_b,  T = sum (b_local+1) B_b          (32 additions deep)
+//   6. k_pip_bits     sum_c c S_c over the 2048 chunks of a window by the BITS of c: workgroup per (window, bit k) tree-adds
+//                     the S_c with bit k set (plus one workgroup for sum_c T_c) -- 12 additions deep instead of the 128 + 8 x 15
+//                     of the round-2 running sums;  k_pip_windows: lane per window, T + 16 sum_k 2^k U_k by Horner
 //   host: Horner over the 16 window sums.
 // HBM traffic is dominated by step 4: every base is gathered once per window (64 B x N x 16), on top of the
 // algorithmic 96 B x N; lanes own equal-size segments of the sorted lists, so the load is balanced whatever the scalar
@@ -24,7 +32,10 @@
 namespace spp {
 
 static constexpr uint32_t PIP_C = 16, PIP_W = 16, PIP_B = 1u << (PIP_C - 1);   // 2^15 buckets per window
-static constexpr uint32_t PIP_CHUNK = 64, PIP_NCHUNK = PIP_B / PIP_CHUNK;
+static constexpr uint32_t PIP_CHUNK = 16, PIP_NCHUNK = PIP_B / PIP_CHUNK, PIP_CHUNK_BITS = 11;   // 2048 chunks of 16 buckets
+static constexpr uint32_t PIP_SLOTS = PIP_CHUNK_BITS + 1;     // per window: sum T_c, then sum of the S_c with bit k of c set
+static constexpr uint32_t PIP_FINE_BITS = 7, PIP_FINE = 1u << PIP_FINE_BITS, PIP_COARSE = PIP_B >> PIP_FINE_BITS;
+static constexpr uint32_t PIP_PART = 16384;                   // entries per sorting workgroup: 1024 lanes x 16
 
 // Signed 16-bit window digits of a canonical scalar, fold sign applied: point i contributes dig[j] * 2^(16 j) * P_i with
 // dig[j] in [-2^15, 2^15 - 1] (int16).  The scalar is folded to |s| <= (r-1)/2 and recoded from the bottom; a window value of
@@ -74,18 +85,13 @@ __global__ void __launch_bounds__(1024) k_pip_count(const int16_t* __restrict__ 
   uint32_t* out = hist_tile + ((size_t)j * ntiles + tile) * PIP_B;
   for (uint32_t b = t; b < PIP_B; b += 1024) out[b] = lh[b];
 }
-// lane per (window, bucket): hist = total over the tiles; hist_tile[tile] becomes the exclusive prefix over the tiles
-__global__ void __launch_bounds__(256) k_pip_totals(uint32_t ntiles, uint32_t* __restrict__ hist_tile, uint32_t* __restrict__ hist) {
+// lane per (window, bucket): hist = total over the tiles
+__global__ void __launch_bounds__(256) k_pip_totals(uint32_t ntiles, const uint32_t* __restrict__ hist_tile, uint32_t* __restrict__ hist) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= PIP_W * PIP_B) return;
   const uint32_t j = g / PIP_B, b = g % PIP_B;
   uint32_t run = 0;
-  for (uint32_t tile = 0; tile < ntiles; tile++) {
-    uint32_t* p = hist_tile + ((size_t)j * ntiles + tile) * PIP_B + b;
-    const uint32_t v = *p;
-    *p = run;
-    run += v;
-  }
+  for (uint32_t tile = 0; tile < ntiles; tile++) run += hist_tile[((size_t)j * ntiles + tile) * PIP_B + b];
   hist[g] = run;
 }
 
@@ -109,25 +115,105 @@ __global__ void __launch_bounds__(1024) k_pip_scan(const uint32_t* __restrict__ 
   SPP_UNROLL for (int k = 0; k < 32; k++) o[k] = base + local[k];
 }
 
-__global__ void __launch_bounds__(1024) k_pip_scatter(const int16_t* __restrict__ digits, uint32_t n, uint32_t ntiles,
-                                                      const uint32_t* __restrict__ offs, const uint32_t* __restrict__ hist_tile,
-                                                      uint32_t* __restrict__ sorted) {
-  __shared__ uint32_t cur[PIP_B];                             // 128 KB: next free slot of every bucket for THIS tile
-  const uint32_t j = blockIdx.x / ntiles, tile = blockIdx.x % ntiles, t = threadIdx.x;
-  const uint32_t* pre = hist_tile + ((size_t)j * ntiles + tile) * PIP_B;
-  for (uint32_t b = t; b < PIP_B; b += 1024) cur[b] = offs[j * PIP_B + b] + pre[b];
+// next free slot of every coarse bin (level 1) and of every bucket (level 2), window-relative
+__global__ void __launch_bounds__(256) k_pip_cursors(const uint32_t* __restrict__ offs, uint32_t* __restrict__ cur1, uint32_t* __restrict__ cur2) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= PIP_W * PIP_B) return;
+  const uint32_t o = offs[g];
+  cur2[g] = o;
+  if ((g & (PIP_FINE - 1)) == 0) cur1[g >> PIP_FINE_BITS] = o;
+}
+
+// Level 1: workgroup per (window, piece of PIP_PART points).  Phase 1 ranks every entry inside its coarse bin (LDS atomic, the
+// returned count is the rank); phase 2 claims cnt[bin] slots of the bin's global range with ONE atomic per bin; phase 3 writes
+// (index | sign) and the fine key to base + rank.  All stores to a run happen between two barriers of one workgroup.
+__global__ void __launch_bounds__(1024) k_pip_part1(const int16_t* __restrict__ digits, uint32_t n, uint32_t nparts,
+                                                    uint32_t* __restrict__ cur1, uint32_t* __restrict__ l1_idx, uint8_t* __restrict__ l1_key) {
+  __shared__ uint32_t cnt[PIP_COARSE];
+  const uint32_t j = blockIdx.x / nparts, part = blockIdx.x % nparts, t = threadIdx.x;
+  if (t < PIP_COARSE) cnt[t] = 0;
   __syncthreads();
   const int16_t* dg = digits + (size_t)j * n;
-  uint32_t* out = sorted + (size_t)j * n;
-  const uint32_t lo = tile << PIP_TILE_LOG, hi = min(n, lo + PIP_TILE);
-  for (uint32_t i = lo + t; i < hi; i += 1024) {
-    const int16_t v = dg[i];
+  const uint32_t lo = part * PIP_PART;
+  uint32_t ent[PIP_PART / 1024], kr[PIP_PART / 1024];         // entry; bucket << 16 | rank (rank < 2^14)
+  SPP_UNROLL for (uint32_t k = 0; k < PIP_PART / 1024; k++) {
+    const uint32_t i = lo + k * 1024 + t;
+    const int16_t v = i < n ? dg[i] : (int16_t)0;
+    kr[k] = 0xffffffffu;
     if (v != 0) {
       uint32_t b, sg;
       pip_decode(v, b, sg);
-      out[atomicAdd(&cur[b], 1u)] = i | sg;
+      ent[k] = i | sg;
+      kr[k] = (b << 16) | atomicAdd(&cnt[b >> PIP_FINE_BITS], 1u);
     }
   }
+  __syncthreads();
+  if (t < PIP_COARSE) {
+    const uint32_t c = cnt[t];
+    if (c) cnt[t] = atomicAdd(&cur1[j * PIP_COARSE + t], c);
+  }
+  __syncthreads();
+  uint32_t* oi = l1_idx + (size_t)j * n;
+  uint8_t* ok = l1_key + (size_t)j * n;
+  SPP_UNROLL for (uint32_t k = 0; k < PIP_PART / 1024; k++) {
+    if (kr[k] != 0xffffffffu) {
+      const uint32_t b = kr[k] >> 16, dest = cnt[b >> PIP_FINE_BITS] + (kr[k] & 0xffffu);
+      oi[dest] = ent[k];
+      ok[dest] = (uint8_t)(b & (PIP_FINE - 1));
+    }
+  }
+}
+
+// Level 2: workgroup per (window, piece of PIP_PART entries of the level-1 list).  The piece lies in coarse bins c_lo..c_hi
+// (one or two for uniform scalars); counter (c - c_lo) * 128 + fine key, same three phases, cursor per bucket.
+__global__ void __launch_bounds__(1024) k_pip_part2(uint32_t n, uint32_t nparts, const uint32_t* __restrict__ offs,
+                                                    const uint32_t* __restrict__ hist, const uint32_t* __restrict__ l1_idx,
+                                                    const uint8_t* __restrict__ l1_key, uint32_t* __restrict__ cur2,
+                                                    uint32_t* __restrict__ sorted) {
+  __shared__ uint32_t cnt[PIP_B];                             // 128 KB; only (c_hi - c_lo + 1) * 128 words are touched
+  __shared__ uint32_t cstart[PIP_COARSE + 1];
+  const uint32_t j = blockIdx.x / nparts, part = blockIdx.x % nparts, t = threadIdx.x;
+  const uint32_t* o = offs + j * PIP_B;
+  const uint32_t total = o[PIP_B - 1] + hist[j * PIP_B + PIP_B - 1];
+  const uint32_t lo = part * PIP_PART;
+  if (lo >= total) return;                                    // the whole workgroup
+  const uint32_t hi = min(lo + PIP_PART, total);
+  if (t < PIP_COARSE) cstart[t] = o[t << PIP_FINE_BITS];
+  if (t == PIP_COARSE) cstart[PIP_COARSE] = total;
+  __syncthreads();
+  auto bin_of = [&](uint32_t pos) {                           // largest c with cstart[c] <= pos: the (non-empty) bin holding pos
+    uint32_t a = 0, b = PIP_COARSE - 1;
+    while (a < b) {
+      const uint32_t mid = (a + b + 1) >> 1;
+      if (cstart[mid] <= pos) a = mid; else b = mid - 1;
+    }
+    return a;
+  };
+  const uint32_t c_lo = bin_of(lo), c_hi = bin_of(hi - 1), range = (c_hi - c_lo + 1) << PIP_FINE_BITS;
+  for (uint32_t b = t; b < range; b += 1024) cnt[b] = 0;
+  __syncthreads();
+  const uint32_t* li = l1_idx + (size_t)j * n;
+  const uint8_t* lk = l1_key + (size_t)j * n;
+  uint32_t ent[PIP_PART / 1024], kr[PIP_PART / 1024];         // entry; counter << 16 | rank
+  SPP_UNROLL for (uint32_t k = 0; k < PIP_PART / 1024; k++) {
+    const uint32_t pos = lo + k * 1024 + t;
+    kr[k] = 0xffffffffu;
+    if (pos < hi) {
+      const uint32_t c = c_lo == c_hi ? c_lo : bin_of(pos);
+      const uint32_t kk = ((c - c_lo) << PIP_FINE_BITS) + lk[pos];
+      ent[k] = li[pos];
+      kr[k] = (kk << 16) | atomicAdd(&cnt[kk], 1u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t b = t; b < range; b += 1024) {
+    const uint32_t c = cnt[b];
+    if (c) cnt[b] = atomicAdd(&cur2[j * PIP_B + (c_lo << PIP_FINE_BITS) + b], c);
+  }
+  __syncthreads();
+  uint32_t* out = sorted + (size_t)j * n;
+  SPP_UNROLL for (uint32_t k = 0; k < PIP_PART / 1024; k++)
+    if (kr[k] != 0xffffffffu) out[cnt[kr[k] >> 16] + (kr[k] & 0xffffu)] = ent[k];
 }
 
 // Bucket accumulation, robust to skewed digit distributions (real witnesses are mostly small: one window then holds
@@ -237,42 +323,59 @@ __global__ void __launch_bounds__(64) k_pip_chunks(const XYZZ<F>* __restrict__ b
   T[g] = tot;
 }
 
-// window sum = sum_c ( T_c + (64 c) * S_c ); one 64-lane block per window, 8 chunks per lane
+// window sum = sum_c ( T_c + 16 c S_c ),  sum_c c S_c = sum_k 2^k U_k with U_k = sum of the S_c whose chunk number has bit k set.
+// Workgroup (slot, window): slot 0 adds up the T_c, slot 1 + k the S_c with bit k set -- strided partial sums, then an LDS tree.
 template <class F>
-__global__ void __launch_bounds__(64) k_pip_windows(const XYZZ<F>* __restrict__ S, const XYZZ<F>* __restrict__ T, XYZZ<F>* __restrict__ out) {
-  __shared__ XYZZ<F> sh[64];
-  const uint32_t j = blockIdx.x, t = threadIdx.x;
+__global__ void __launch_bounds__(128) k_pip_bits(const XYZZ<F>* __restrict__ S, const XYZZ<F>* __restrict__ T, XYZZ<F>* __restrict__ U) {
+  __shared__ XYZZ<F> sh[128];
+  const uint32_t slot = blockIdx.x, j = blockIdx.y, t = threadIdx.x;
   XYZZ<F> acc = XYZZ<F>::infinity();
-  for (uint32_t c = t; c < PIP_NCHUNK; c += 64) {
-    acc.add(T[j * PIP_NCHUNK + c]);
-    // (64 c) * S_c by double-and-add on the 15-bit multiplier
-    XYZZ<F> s = S[j * PIP_NCHUNK + c], m = XYZZ<F>::infinity();
-    uint32_t k = PIP_CHUNK * c;
-    for (int bit = 14; bit >= 0; bit--) {
-      m.dbl_inplace();
-      if ((k >> bit) & 1) m.add(s);
+  if (slot == 0) {
+    for (uint32_t c = t; c < PIP_NCHUNK; c += 128) acc.add(T[j * PIP_NCHUNK + c]);
+  } else {
+    const uint32_t k = slot - 1;
+    // the chunk numbers with bit k set, enumerated densely: m in [0, NCHUNK / 2) -> insert a 1 at bit k
+    for (uint32_t m = t; m < PIP_NCHUNK / 2; m += 128) {
+      const uint32_t c = ((m >> k) << (k + 1)) | (1u << k) | (m & ((1u << k) - 1));
+      acc.add(S[j * PIP_NCHUNK + c]);
     }
-    acc.add(m);
   }
   sh[t] = acc;
   __syncthreads();
-  for (uint32_t w = 32; w > 0; w >>= 1) {
+  for (uint32_t w = 64; w > 0; w >>= 1) {
     if (t < w) { XYZZ<F> a = sh[t]; a.add(sh[t + w]); sh[t] = a; }
     __syncthreads();
   }
-  if (t == 0) out[j] = sh[0];
+  if (t == 0) U[j * PIP_SLOTS + slot] = sh[0];
+}
+// lane per window: T + 16 (U_0 + 2 U_1 + ... + 2^10 U_10)
+template <class F>
+__global__ void __launch_bounds__(64) k_pip_windows(const XYZZ<F>* __restrict__ U, XYZZ<F>* __restrict__ out) {
+  const uint32_t j = threadIdx.x;
+  if (j >= PIP_W) return;
+  const XYZZ<F>* u = U + j * PIP_SLOTS;
+  XYZZ<F> r = u[PIP_CHUNK_BITS];
+  for (int k = (int)PIP_CHUNK_BITS - 1; k >= 1; k--) {
+    r.dbl_inplace();
+    r.add(u[k]);
+  }
+  for (uint32_t m = PIP_CHUNK; m > 1; m >>= 1) r.dbl_inplace();
+  r.add(u[0]);
+  out[j] = r;
 }
 
-// workspace layout (u32 words unless noted): hist[W*B] | offs[W*B] | hist_tile[W*ntiles*B] | sorted[W*n] | digits (int16 [W][n],
-// padded to whole words) ; then XYZZ: buckets[W*B] | S | T | out[W] | head[W*nseg] | tail[W*nseg]
+// workspace layout (u32 words unless noted): hist[W*B] | offs[W*B] | cur2[W*B] | cur1[W*COARSE] | hist_tile[W*ntiles*B] | sorted[W*n] |
+// l1_idx[W*n] | digits (int16 [W][n], padded to whole words) | l1_key (u8 [W][n], padded) ; then XYZZ: buckets[W*B] | S | T | U[W*SLOTS] |
+// out[W] | head[W*nseg] | tail[W*nseg]
 static uint32_t pip_nseg(uint32_t n) { return (n + PIP_SEG - 1) / PIP_SEG + 1; }
 static uint32_t pip_ntiles(uint32_t n) { return n ? (n + PIP_TILE - 1) / PIP_TILE : 1; }
 static size_t pip_words(uint32_t n) {
-  return (size_t)2 * PIP_W * PIP_B + (size_t)PIP_W * pip_ntiles(n) * PIP_B + (size_t)PIP_W * n + ((size_t)PIP_W * n + 1) / 2;
+  return (size_t)3 * PIP_W * PIP_B + (size_t)PIP_W * PIP_COARSE + (size_t)PIP_W * pip_ntiles(n) * PIP_B + (size_t)2 * PIP_W * n +
+         ((size_t)PIP_W * n + 1) / 2 + ((size_t)PIP_W * n + 3) / 4;
 }
 template <class F>
 static size_t pip_ws_bytes(uint32_t n) {
-  size_t pts = (size_t)PIP_W * PIP_B + 2 * (size_t)PIP_W * PIP_NCHUNK + PIP_W + 2 * (size_t)PIP_W * pip_nseg(n);
+  size_t pts = (size_t)PIP_W * PIP_B + 2 * (size_t)PIP_W * PIP_NCHUNK + (size_t)PIP_W * PIP_SLOTS + PIP_W + 2 * (size_t)PIP_W * pip_nseg(n);
   return ((pip_words(n) * 4 + 255) / 256) * 256 + pts * sizeof(XYZZ<F>);
 }
 size_t pippenger_workspace_bytes(uint32_t n) { return pip_ws_bytes<Fq>(n); }
@@ -283,16 +386,21 @@ uint32_t pippenger_windows() { return PIP_W; }
 template <class F>
 static void launch_pippenger(hipStream_t st, const Affine<F>* bases, const Fr* scalars, uint32_t n, void* workspace, XYZZ<F>** out_windows,
                              hipEvent_t ev0, hipEvent_t ev1) {
-  const uint32_t ntiles = pip_ntiles(n);
+  const uint32_t ntiles = pip_ntiles(n), nparts = n ? (n + PIP_PART - 1) / PIP_PART : 1;
   uint32_t* hist = (uint32_t*)workspace;
   uint32_t* offs = hist + PIP_W * PIP_B;
-  uint32_t* hist_tile = offs + PIP_W * PIP_B;
+  uint32_t* cur2 = offs + PIP_W * PIP_B;
+  uint32_t* cur1 = cur2 + PIP_W * PIP_B;
+  uint32_t* hist_tile = cur1 + PIP_W * PIP_COARSE;
   uint32_t* sorted = hist_tile + (size_t)PIP_W * ntiles * PIP_B;
-  int16_t* digits = (int16_t*)(sorted + (size_t)PIP_W * n);
+  uint32_t* l1_idx = sorted + (size_t)PIP_W * n;
+  int16_t* digits = (int16_t*)(l1_idx + (size_t)PIP_W * n);
+  uint8_t* l1_key = (uint8_t*)((uint32_t*)digits + ((size_t)PIP_W * n + 1) / 2);
   XYZZ<F>* buckets = (XYZZ<F>*)((char*)workspace + ((pip_words(n) * 4 + 255) / 256) * 256);
   XYZZ<F>* S = buckets + (size_t)PIP_W * PIP_B;
   XYZZ<F>* T = S + (size_t)PIP_W * PIP_NCHUNK;
-  XYZZ<F>* out = T + (size_t)PIP_W * PIP_NCHUNK;
+  XYZZ<F>* U = T + (size_t)PIP_W * PIP_NCHUNK;
+  XYZZ<F>* out = U + (size_t)PIP_W * PIP_SLOTS;
   const uint32_t nseg = pip_nseg(n);
   XYZZ<F>* head = out + PIP_W;
   XYZZ<F>* tail = head + (size_t)PIP_W * nseg;
@@ -300,14 +408,17 @@ static void launch_pippenger(hipStream_t st, const Affine<F>* bases, const Fr* s
   hipLaunchKernelGGL(k_pip_count, dim3(PIP_W * ntiles), dim3(1024), 0, st, digits, n, ntiles, hist_tile);
   hipLaunchKernelGGL(k_pip_totals, dim3(PIP_W * PIP_B / 256), dim3(256), 0, st, ntiles, hist_tile, hist);
   hipLaunchKernelGGL(k_pip_scan, dim3(PIP_W), dim3(1024), 0, st, hist, offs);
-  hipLaunchKernelGGL(k_pip_scatter, dim3(PIP_W * ntiles), dim3(1024), 0, st, digits, n, ntiles, offs, hist_tile, sorted);
+  hipLaunchKernelGGL(k_pip_cursors, dim3(PIP_W * PIP_B / 256), dim3(256), 0, st, offs, cur1, cur2);
+  hipLaunchKernelGGL(k_pip_part1, dim3(PIP_W * nparts), dim3(1024), 0, st, digits, n, nparts, cur1, l1_idx, l1_key);
+  hipLaunchKernelGGL(k_pip_part2, dim3(PIP_W * nparts), dim3(1024), 0, st, n, nparts, offs, hist, l1_idx, l1_key, cur2, sorted);
   if (ev0) hipEventRecord(ev0, st);
   hipLaunchKernelGGL(k_pip_segments<F>, dim3((PIP_W * nseg + 255) / 256), dim3(256), 0, st, bases, n, nseg, offs, hist, sorted, buckets,
                      head, tail);
   if (ev1) hipEventRecord(ev1, st);
   hipLaunchKernelGGL(k_pip_fixup<F>, dim3(PIP_W * PIP_B / 256), dim3(256), 0, st, nseg, offs, hist, buckets, head, tail);
   hipLaunchKernelGGL(k_pip_chunks<F>, dim3(PIP_W * PIP_NCHUNK / 64), dim3(64), 0, st, buckets, S, T);
-  hipLaunchKernelGGL(k_pip_windows<F>, dim3(PIP_W), dim3(64), 0, st, S, T, out);
+  hipLaunchKernelGGL(k_pip_bits<F>, dim3(PIP_SLOTS, PIP_W), dim3(128), 0, st, S, T, U);
+  hipLaunchKernelGGL(k_pip_windows<F>, dim3(1), dim3(64), 0, st, U, out);
   *out_windows = out;
 }
 void launch_pippenger_g1(hipStream_t st, const G1Affine* bases, const Fr* scalars, uint32_t n, void* workspace, G1XYZZ** out_windows,
