@@ -1,0 +1,25 @@
+#!/bin/bash
+# Round-3 measurement recipe of the 2^24-point Pippenger MSM (run on the GPU box through gpurun, from the repo root):
+#   bash profiles/run_pippenger_profile.sh <tag>
+# kernel stats of the whole leg, then FETCH_SIZE / WRITE_SIZE (separate passes) and the SQ counters on the uniform MSM alone.
+set -e
+TAG=$1
+export TMPDIR=/tmp
+OUT=$PWD/gpurun_out
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o pip -- python3 profiles/pippenger_leg_only.py 5 > $OUT/${TAG}_leg.json 2> $OUT/${TAG}_leg.err
+echo "stats done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats_u -o pip -- python3 profiles/pippenger_leg_only.py 5 uniform > $OUT/${TAG}_leg_u.json 2> $OUT/${TAG}_leg_u.err
+echo "uniform stats done"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -o pmc -- python3 profiles/pippenger_leg_only.py 2 uniform > $OUT/${TAG}_pmc_fetch.log 2>&1
+echo "fetch done"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -o pmc -- python3 profiles/pippenger_leg_only.py 2 uniform > $OUT/${TAG}_pmc_write.log 2>&1
+echo "write done"
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_valu -o pmc -- python3 profiles/pippenger_leg_only.py 2 uniform > $OUT/${TAG}_pmc_valu.log 2>&1
+echo "valu done"
+mkdir -p $OUT/${TAG}_summary
+python3 profiles/summarize_pmc_valu.py $OUT/${TAG}_pmc_valu $OUT/${TAG}_summary/round3_pippenger_pmc_valu.json > /dev/null
+python3 profiles/summarize_pmc.py $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_summary/round3_pippenger_pmc_hbm_kernels.json
+cp $(find $OUT/${TAG}_stats -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_summary/round3_kernel_stats_pippenger.csv
+cp $(find $OUT/${TAG}_stats_u -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_summary/round3_kernel_stats_pippenger_uniform.csv
+cp $OUT/${TAG}_leg.json $OUT/${TAG}_summary/round3_pippenger_leg_under_rocprof.json
+rm -rf $OUT/${TAG}_stats $OUT/${TAG}_stats_u $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_valu

@@ -28,6 +28,7 @@
 // distribution (uniform: N / 2^15 points per bucket; witness-like: most points in a few hundred buckets of window 0).
 #include "kernels.hpp"
 #include "f29.hpp"
+#include <cstdlib>
 
 namespace spp {
 
@@ -127,6 +128,8 @@ __global__ void __launch_bounds__(256) k_pip_cursors(const uint32_t* __restrict_
 // Level 1: workgroup per (window, piece of PIP_PART points).  Phase 1 ranks every entry inside its coarse bin (LDS atomic, the
 // returned count is the rank); phase 2 claims cnt[bin] slots of the bin's global range with ONE atomic per bin; phase 3 writes
 // (index | sign) and the fine key to base + rank.  All stores to a run happen between two barriers of one workgroup.
+// PACKED (n <= 2^24): the 7 key bits travel in bits 24..30 of the entry, no byte array.
+template <bool PACKED>
 __global__ void __launch_bounds__(1024) k_pip_part1(const int16_t* __restrict__ digits, uint32_t n, uint32_t nparts,
                                                     uint32_t* __restrict__ cur1, uint32_t* __restrict__ l1_idx, uint8_t* __restrict__ l1_key) {
   __shared__ uint32_t cnt[PIP_COARSE];
@@ -158,14 +161,18 @@ __global__ void __launch_bounds__(1024) k_pip_part1(const int16_t* __restrict__ 
   SPP_UNROLL for (uint32_t k = 0; k < PIP_PART / 1024; k++) {
     if (kr[k] != 0xffffffffu) {
       const uint32_t b = kr[k] >> 16, dest = cnt[b >> PIP_FINE_BITS] + (kr[k] & 0xffffu);
-      oi[dest] = ent[k];
-      ok[dest] = (uint8_t)(b & (PIP_FINE - 1));
+      if constexpr (PACKED) oi[dest] = ent[k] | ((b & (PIP_FINE - 1)) << 24);
+      else {
+        oi[dest] = ent[k];
+        ok[dest] = (uint8_t)(b & (PIP_FINE - 1));
+      }
     }
   }
 }
 
 // Level 2: workgroup per (window, piece of PIP_PART entries of the level-1 list).  The piece lies in coarse bins c_lo..c_hi
 // (one or two for uniform scalars); counter (c - c_lo) * 128 + fine key, same three phases, cursor per bucket.
+template <bool PACKED>
 __global__ void __launch_bounds__(1024) k_pip_part2(uint32_t n, uint32_t nparts, const uint32_t* __restrict__ offs,
                                                     const uint32_t* __restrict__ hist, const uint32_t* __restrict__ l1_idx,
                                                     const uint8_t* __restrict__ l1_key, uint32_t* __restrict__ cur2,
@@ -200,8 +207,13 @@ __global__ void __launch_bounds__(1024) k_pip_part2(uint32_t n, uint32_t nparts,
     kr[k] = 0xffffffffu;
     if (pos < hi) {
       const uint32_t c = c_lo == c_hi ? c_lo : bin_of(pos);
-      const uint32_t kk = ((c - c_lo) << PIP_FINE_BITS) + lk[pos];
-      ent[k] = li[pos];
+      uint32_t en = li[pos], fine;
+      if constexpr (PACKED) {
+        fine = (en >> 24) & (PIP_FINE - 1);
+        en &= 0x80ffffffu;
+      } else fine = lk[pos];
+      const uint32_t kk = ((c - c_lo) << PIP_FINE_BITS) + fine;
+      ent[k] = en;
       kr[k] = (kk << 16) | atomicAdd(&cnt[kk], 1u);
     }
   }
@@ -265,17 +277,17 @@ __global__ void __launch_bounds__(256) k_pip_segments(const Affine<F>* __restric
     else if (continues_after) tail[g] = r;
     else buckets[(size_t)j * PIP_B + b] = r;
   };
-  // software pipeline: the index and the (randomly placed, 64 B) base of entry k + 1 are requested before the ~2.3 K
+  // software pipeline: the (randomly placed, 64 B) base of entry k + 1 is requested before the ~2.3 K
   // instructions of the addition of entry k, so the HBM round trip of the gather hides behind arithmetic of the same lane
-  uint32_t e = seg[pos];
+  // (the index of entry k + 2 is requested in the same step: the gather of k + 1 never waits for its own address)
+  uint32_t e = seg[pos], e_ahead = pos + 1 < end ? seg[pos + 1] : 0u;
   Affine<F> p = bases[e & 0x7fffffffu];
   for (uint32_t k = pos; k < end; k++) {
     const uint32_t e_cur = e;
     const Affine<F> p_cur = p;
-    if (k + 1 < end) {
-      e = seg[k + 1];
-      p = bases[e & 0x7fffffffu];
-    }
+    e = e_ahead;
+    if (k + 1 < end) p = bases[e & 0x7fffffffu];
+    if (k + 2 < end) e_ahead = seg[k + 2];
     if (k == bend) {                                       // next non-empty bucket starts here
       flush(false);
       acc = Acc::infinity();
@@ -289,23 +301,61 @@ __global__ void __launch_bounds__(256) k_pip_segments(const Affine<F>* __restric
   }
   flush(bend > end);
 }
-// lane per (window, bucket): empty buckets -> infinity; buckets spanning several segments -> tail[s0] + head[s0+1..s1]
+// lane per (window, bucket): empty buckets -> infinity; buckets spanning several segments -> tail[s0] + head[s0+1..s1].
+// A bucket that spans more than PIP_FIX_SEQ segments (byte-sized witness values: tens of thousands of points in each of 255
+// buckets of window 0) is summed by a whole wave of k_pip_fixup_heavy -- strided partial sums, then a shuffle tree -- instead of
+// one lane adding hundreds of partials in sequence.
+static constexpr uint32_t PIP_FIX_SEQ = 12;
+template <class T>
+__device__ __forceinline__ T pip_shfl_down(const T& v, int delta) {
+  static_assert(sizeof(T) % 4 == 0, "word-sized");
+  T r;
+  const uint32_t* s = reinterpret_cast<const uint32_t*>(&v);
+  uint32_t* d = reinterpret_cast<uint32_t*>(&r);
+  SPP_UNROLL for (uint32_t i = 0; i < sizeof(T) / 4; i++) d[i] = (uint32_t)__shfl_down((int)s[i], delta, 64);
+  return r;
+}
 template <class F>
 __global__ void __launch_bounds__(256) k_pip_fixup(uint32_t nseg, const uint32_t* __restrict__ offs, const uint32_t* __restrict__ hist,
                                                    XYZZ<F>* __restrict__ buckets, const XYZZ<F>* __restrict__ head,
                                                    const XYZZ<F>* __restrict__ tail) {
-  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= PIP_W * PIP_B) return;
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;       // the grid is exactly PIP_W * PIP_B lanes
   const uint32_t j = g / PIP_B, cnt = hist[g];
-  if (cnt == 0) {
-    buckets[g] = XYZZ<F>::infinity();
-    return;
+  uint32_t s0 = 0, s1 = 0;
+  if (cnt == 0) buckets[g] = XYZZ<F>::infinity();
+  else {
+    s0 = offs[g] / PIP_SEG;
+    s1 = (offs[g] + cnt - 1) / PIP_SEG;
   }
+  if (s1 != s0 && s1 - s0 <= PIP_FIX_SEQ) {                      // (s0 == s1: written directly by its segment lane)
+    XYZZ<F> acc = tail[(size_t)j * nseg + s0];
+    for (uint32_t s = s0 + 1; s <= s1; s++) acc.add(head[(size_t)j * nseg + s]);
+    buckets[g] = acc;
+  }
+}
+// wave per (window, bucket): the heavy buckets (all other waves leave at once; heavy buckets are neighbours -- the byte values of
+// window 0 -- so a lane-per-bucket kernel would serialise 64 of them in every wave it does not leave idle)
+template <class F>
+__global__ void __launch_bounds__(256) k_pip_fixup_heavy(uint32_t nseg, const uint32_t* __restrict__ offs, const uint32_t* __restrict__ hist,
+                                                         XYZZ<F>* __restrict__ buckets, const XYZZ<F>* __restrict__ head,
+                                                         const XYZZ<F>* __restrict__ tail) {
+  const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;      // the grid is exactly PIP_W * PIP_B waves
+  const uint32_t j = g / PIP_B, cnt = hist[g];
+  if (cnt == 0) return;
   const uint32_t s0 = offs[g] / PIP_SEG, s1 = (offs[g] + cnt - 1) / PIP_SEG;
-  if (s0 == s1) return;                                    // written directly by its segment lane
-  XYZZ<F> acc = tail[(size_t)j * nseg + s0];
-  for (uint32_t s = s0 + 1; s <= s1; s++) acc.add(head[(size_t)j * nseg + s]);
-  buckets[g] = acc;
+  if (s1 - s0 <= PIP_FIX_SEQ) return;
+  const XYZZ<F>* hd = head + (size_t)j * nseg;
+  XYZZ<F> acc = XYZZ<F>::infinity();
+  for (uint32_t s = s0 + 1 + lane; s <= s1; s += 64) acc.add(hd[s]);
+  for (int d = 32; d > 0; d >>= 1) {
+    const XYZZ<F> o = pip_shfl_down(acc, d);
+    if ((int)lane < d) acc.add(o);
+  }
+  if (lane == 0) {
+    XYZZ<F> r = tail[(size_t)j * nseg + s0];
+    r.add(acc);
+    buckets[g] = r;
+  }
 }
 
 // chunk c of window j: S = sum_b B_b, T = sum_b (b_local + 1) B_b  (running-sum trick from the top bucket down)
@@ -409,13 +459,19 @@ static void launch_pippenger(hipStream_t st, const Affine<F>* bases, const Fr* s
   hipLaunchKernelGGL(k_pip_totals, dim3(PIP_W * PIP_B / 256), dim3(256), 0, st, ntiles, hist_tile, hist);
   hipLaunchKernelGGL(k_pip_scan, dim3(PIP_W), dim3(1024), 0, st, hist, offs);
   hipLaunchKernelGGL(k_pip_cursors, dim3(PIP_W * PIP_B / 256), dim3(256), 0, st, offs, cur1, cur2);
-  hipLaunchKernelGGL(k_pip_part1, dim3(PIP_W * nparts), dim3(1024), 0, st, digits, n, nparts, cur1, l1_idx, l1_key);
-  hipLaunchKernelGGL(k_pip_part2, dim3(PIP_W * nparts), dim3(1024), 0, st, n, nparts, offs, hist, l1_idx, l1_key, cur2, sorted);
+  if (n <= (1u << 24) && !getenv("SPP_PIP_UNPACKED")) {     // (the switch lets the tests run the large-n form on small inputs)
+    hipLaunchKernelGGL(k_pip_part1<true>, dim3(PIP_W * nparts), dim3(1024), 0, st, digits, n, nparts, cur1, l1_idx, l1_key);
+    hipLaunchKernelGGL(k_pip_part2<true>, dim3(PIP_W * nparts), dim3(1024), 0, st, n, nparts, offs, hist, l1_idx, l1_key, cur2, sorted);
+  } else {
+    hipLaunchKernelGGL(k_pip_part1<false>, dim3(PIP_W * nparts), dim3(1024), 0, st, digits, n, nparts, cur1, l1_idx, l1_key);
+    hipLaunchKernelGGL(k_pip_part2<false>, dim3(PIP_W * nparts), dim3(1024), 0, st, n, nparts, offs, hist, l1_idx, l1_key, cur2, sorted);
+  }
   if (ev0) hipEventRecord(ev0, st);
   hipLaunchKernelGGL(k_pip_segments<F>, dim3((PIP_W * nseg + 255) / 256), dim3(256), 0, st, bases, n, nseg, offs, hist, sorted, buckets,
                      head, tail);
   if (ev1) hipEventRecord(ev1, st);
   hipLaunchKernelGGL(k_pip_fixup<F>, dim3(PIP_W * PIP_B / 256), dim3(256), 0, st, nseg, offs, hist, buckets, head, tail);
+  hipLaunchKernelGGL(k_pip_fixup_heavy<F>, dim3(PIP_W * PIP_B / 4), dim3(256), 0, st, nseg, offs, hist, buckets, head, tail);
   hipLaunchKernelGGL(k_pip_chunks<F>, dim3(PIP_W * PIP_NCHUNK / 64), dim3(64), 0, st, buckets, S, T);
   hipLaunchKernelGGL(k_pip_bits<F>, dim3(PIP_SLOTS, PIP_W), dim3(128), 0, st, S, T, U);
   hipLaunchKernelGGL(k_pip_windows<F>, dim3(1), dim3(64), 0, st, U, out);

@@ -63,6 +63,29 @@ __global__ void __launch_bounds__(256) k_gather(const uint4* __restrict__ table,
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = 1;           // never true for the pattern below: keeps the loads
 }
 
+// The discriminating case: 64 B at a random 128-byte-aligned place, then -- at an address that DEPENDS on what came back, so
+// strictly later -- the other 64 B of the same line.  One fabric request per place (FETCH_SIZE = 64 B per place) means the first
+// request brought the whole line: a lone 64-byte gather moves 128 B.  Two requests (128 B per place) mean the L2 fills 64-byte halves.
+__global__ void __launch_bounds__(256) k_gather_halves(const uint4* __restrict__ table, uint64_t lines, uint32_t per_lane, uint32_t* __restrict__ sink) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint4 acc = {0, 0, 0, 0};
+  for (uint32_t k = 0; k < per_lane; k++) {
+    const uint64_t line = mix(g * 0x9e3779b97f4a7c15ull + k) % lines;
+    const uint4* p = table + line * 8;
+    uint4 v[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) v[w] = p[w];
+    const uint32_t zero = (~(v[0].x & v[1].x & v[2].x & v[3].x)) & 1u;       // every table word is odd: always 0, unknown to the compiler
+    const uint4* q = p + 4 + zero * 8;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const uint4 u = q[w];
+      acc.x ^= v[w].x ^ u.x; acc.y ^= v[w].y ^ u.y; acc.z ^= v[w].z ^ u.z; acc.w ^= v[w].w ^ u.w;
+    }
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = 1;
+}
+
 __global__ void __launch_bounds__(256) k_stream(const uint4* __restrict__ table, uint64_t n16, uint32_t* __restrict__ sink) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   uint4 acc = {0, 0, 0, 0};
@@ -76,7 +99,7 @@ __global__ void __launch_bounds__(256) k_stream(const uint4* __restrict__ table,
 __global__ void k_fill(uint4* t, uint64_t n16) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
-    const uint32_t v = (uint32_t)mix(i) | 1u;
+    const uint32_t v = (uint32_t)mix(i) | 1u;                                  // odd, and so are its odd multiples
     t[i] = uint4{v, v * 3u, v * 5u, v * 7u};
   }
 }
@@ -114,6 +137,9 @@ int main() {
   run<32, true>(table, bytes, sink, "k_gather4<32>");
   run<64, true>(table, bytes, sink, "k_gather4<64>");
   run<128, true>(table, bytes, sink, "k_gather4<128>");
+  hipLaunchKernelGGL(k_gather_halves, dim3(256 * 64), dim3(256), 0, 0, table, bytes / 128, 16u, sink);
+  CHECK(hipDeviceSynchronize());
+  printf("k_gather_halves ran: 67108864 places, 64 B + the other 64 B of the same line afterwards (read its FETCH_SIZE under rocprofv3)\n");
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   hipLaunchKernelGGL(k_stream, dim3(4096), dim3(256), 0, 0, table, bytes / 16, sink);

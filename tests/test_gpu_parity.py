@@ -873,6 +873,31 @@ def test_pippenger_matches_oracle_and_is_linear(ctx):
     assert r3 == out.raw
 
 
+def test_pippenger_sort_forms_agree(ctx, monkeypatch):
+    """The two-level bucket sort (kernels_pippenger.hip step 3) carries the 7 fine key bits inside the entry while n <= 2^24 and in a
+    byte array beyond; SPP_PIP_UNPACKED=1 runs the second form on small inputs.  Same sums, oracle-checked at 300 points."""
+    from oracle import bn254 as B, native
+    import ctypes
+    rng = random.Random(22)
+    pts, p = [], B.G1_GEN
+    for i in range(300):
+        p = B.g1_add(p, B.g1_mul(B.G1_GEN, rng.randrange(1, 1 << 64)))
+        pts.append(p)
+    bases = b"".join(B.g1_to_bytes(q) for q in pts)
+    sc = [rng.randrange(B.R) for _ in range(300)]
+    sc[:6] = [0, 1, B.R - 1, 0x8000, 0xffff, 1 << 252]
+    sc[100:164] = [77] * 64
+    out = ctypes.create_string_buffer(64)
+    native.lib().orc_msm_g1(bases, b"".join(s.to_bytes(32, "big") for s in sc), 300, ctypes.cast(out, ctypes.c_void_p))
+    packed = ctx.msm_g1_pippenger(bases, sc)
+    big_packed, _, _ = ctx.msm_g1_pippenger_bench(1 << 17, seed=3)
+    skew_packed, _, _ = ctx.msm_g1_pippenger_bench(1 << 17, seed=3, small_permille=900)
+    monkeypatch.setenv("SPP_PIP_UNPACKED", "1")
+    assert ctx.msm_g1_pippenger(bases, sc) == packed == out.raw
+    assert ctx.msm_g1_pippenger_bench(1 << 17, seed=3)[0] == big_packed
+    assert ctx.msm_g1_pippenger_bench(1 << 17, seed=3, small_permille=900)[0] == skew_packed
+
+
 def test_pippenger_shards_add_up_to_the_whole_msm(ctx):
     """spp_msm_g1_pippenger_bench_shard: the partial sums of three uneven contiguous shares of the synthetic 2^16-point MSM add up to
     the MSM of all points (what spp/multi.py msm_g1_sharded gathers over RCCL on a multi-GPU node), and a share of everything is the
@@ -896,10 +921,10 @@ def test_pippenger_skewed_scalars(ctx):
     for i in range(200):
         p = B.g1_add(p, B.g1_mul(B.G1_GEN, rng.randrange(1, 1 << 64)))
         pts.append(p)
-    n = 5000
+    n = 8000                 # 5 300 + 300 entries in one bucket: 22 segments, summed by a whole wave in k_pip_fixup (> PIP_FIX_SEQ)
     idx = [rng.randrange(200) for _ in range(n)]
     bases = b"".join(B.g1_to_bytes(pts[i]) for i in idx)
-    sc = [7] * 2300 + [B.R - 7] * 300 + [rng.randrange(256) for _ in range(1500)] + [rng.randrange(B.R) for _ in range(900)]
+    sc = [7] * 5300 + [B.R - 7] * 300 + [rng.randrange(256) for _ in range(1500)] + [rng.randrange(B.R) for _ in range(900)]
     rng.shuffle(sc)
     out = ctypes.create_string_buffer(64)
     native.lib().orc_msm_g1(bases, b"".join(s.to_bytes(32, "big") for s in sc), n, ctypes.cast(out, ctypes.c_void_p))
