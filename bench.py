@@ -241,9 +241,9 @@ def pippenger_leg(ctx, iters=10):
     native.lib().orc_msm_g1(bases, sc, ns, ctypes.cast(out, ctypes.c_void_p))
     cpu_s = time.perf_counter() - t0
     traffic = None
-    try:   # PMC passes of this leg, committed under profiles/
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "round2_pippenger_pmc_hbm.json")))
-        if pmc.get("points") == n:
+    try:   # PMC passes of this leg (profiles/run_pippenger_profile.sh), valid for the library they were taken on
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "round3_pippenger_pmc_hbm.json")))
+        if pmc.get("points") == n and pmc.get("libspp_sha256") == libspp_sha256():
             traffic = pmc["hbm_bytes_per_msm"]
     except Exception:
         pass

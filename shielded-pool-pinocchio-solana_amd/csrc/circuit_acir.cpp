@@ -27,6 +27,7 @@
 //     bound only by the AssertZero and RANGE opcodes that follow them.
 //   MultiScalarMul(G; lo, hi): the fixed-base Grumpkin ladder of circuit.cpp over the 256 bits of (lo, hi).
 // Builder::finish() adds the lookup argument with its BSB22 commitment, so the 388-byte proof layout is kept.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <map>

@@ -57,6 +57,12 @@ struct DevCircuit {
   const uint32_t* sm_row_out;   // matrix (0 = A, 1 = B, 2 = C) << 30 | constraint
   uint32_t sm_nrows;
   const uint8_t* row_small;     // per constraint: bit 0 A, bit 1 B, bit 2 C is a small row (nullptr: none)
+  // LONG rows (more than LONG_ROW_MIN terms and not small: the audit circuit's lookup sum has 6 720): one lane per (run, proof)
+  // would leave 32 waves walking such a row alone for milliseconds after the rest of the grid has drained.  k_spmv_long_rows
+  // evaluates them first, 16 lanes per (row, proof) meeting through LDS, and they carry the same "already in abc" bits.
+  const uint32_t* lg_rows;      // (matrix << 30) | constraint
+  uint32_t lg_n;
+  const uint8_t* row_long;      // the bits of the long rows alone (what k_spmv_check reads when the small-row path is off)
   // hash constants (Montgomery)
   const Fr* pos3_rc;  const Fr* pos3_mds;   // t=3: 195 rc, 9 mds (row-major)
   const Fr* pos5_rc;  const Fr* pos5_mds;   // t=5: 340 rc, 25 mds

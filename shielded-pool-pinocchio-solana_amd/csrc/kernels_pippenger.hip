@@ -11,11 +11,11 @@
 //      to a line of its own (6.8 GB of HBM writes for 1.07 GB of payload, 6.8 ms): a 2^20-point tile puts 32 entries into each
 //      bucket, spread over the whole pass.  Now each pass has few destinations per workgroup, all written between two barriers:
 //      k_pip_part1    workgroup per (window, 16 K points): ranks within the 256 COARSE bins (bucket >> 7) from LDS atomics,
-//                     one global atomic per bin and workgroup claims the run, then (index | sign) and the 7 fine key bits go
-//                     out in runs of ~64 entries (256 B + 64 B) that the L2 completes before it writes them back
+//                     one global atomic per bin and workgroup claims the run, the entries (index | sign | 7 fine key bits) are
+//                     put in bin order in LDS and leave as runs of ~64 entries (256 B), consecutive lanes on consecutive words
 //      k_pip_part2    workgroup per (window, 16 K entries of that list): the same by bucket inside the coarse bins the
 //                     piece touches (normally one or two: <= 256 counters; a skewed window may put many small bins into
-//                     one piece, the counter array covers all 2^15 buckets), runs of ~64 entries into the final list
+//                     one piece, taken 64 bins at a time), runs of ~64 entries into the final list
 //   4. k_pip_segments lane per 256-entry segment of a window's sorted list: gathers its points (64 B each) and folds them
 //                     with mixed additions per bucket; k_pip_fixup joins the buckets that span segments
 //   5. k_pip_chunks   lane per 16-bucket chunk: running sums  S = sum B_b,  T = sum (b_local+1) B_b          (32 additions deep)
@@ -126,14 +126,36 @@ __global__ void __launch_bounds__(256) k_pip_cursors(const uint32_t* __restrict_
 }
 
 // Level 1: workgroup per (window, piece of PIP_PART points).  Phase 1 ranks every entry inside its coarse bin (LDS atomic, the
-// returned count is the rank); phase 2 claims cnt[bin] slots of the bin's global range with ONE atomic per bin; phase 3 writes
-// (index | sign) and the fine key to base + rank.  All stores to a run happen between two barriers of one workgroup.
+// returned count is the rank); phase 2 turns the counts into local offsets (scan) and claims cnt[bin] slots of the bin's global
+// range with ONE atomic per bin; phase 3 puts the entries in bin order into an LDS staging buffer; phase 4 copies the buffer
+// out with consecutive lanes on consecutive addresses -- a run of ~64 entries is two full-line stores instead of 64 four-byte
+// ones (the unstaged version left 2.3 GB of HBM writes for 1.07 GB of entries: the L2 did not always see a run complete).
 // PACKED (n <= 2^24): the 7 key bits travel in bits 24..30 of the entry, no byte array.
+__device__ __forceinline__ uint32_t pip_wave_incl_scan(uint32_t v, uint32_t lane) {
+  SPP_UNROLL for (uint32_t d = 1; d < 64; d <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+// largest i in [0, count) with pre[i] <= s   (pre = non-decreasing exclusive prefix; empty slots repeat the next start)
+__device__ __forceinline__ uint32_t pip_slot_of(const uint32_t* pre, uint32_t count, uint32_t s) {
+  uint32_t a = 0, b = count - 1;
+  while (a < b) {
+    const uint32_t mid = (a + b + 1) >> 1;
+    if (pre[mid] <= s) a = mid; else b = mid - 1;
+  }
+  return a;
+}
 template <bool PACKED>
 __global__ void __launch_bounds__(1024) k_pip_part1(const int16_t* __restrict__ digits, uint32_t n, uint32_t nparts,
                                                     uint32_t* __restrict__ cur1, uint32_t* __restrict__ l1_idx, uint8_t* __restrict__ l1_key) {
-  __shared__ uint32_t cnt[PIP_COARSE];
-  const uint32_t j = blockIdx.x / nparts, part = blockIdx.x % nparts, t = threadIdx.x;
+  __shared__ uint32_t cnt[PIP_COARSE];                        // counts, then the local exclusive prefix
+  __shared__ uint32_t gb[PIP_COARSE];                         // where the bin's run starts in the window's list
+  __shared__ uint32_t wsum[4];
+  __shared__ uint32_t stage[PIP_PART];                        // 64 KB
+  __shared__ uint8_t stagek[PACKED ? 4 : PIP_PART];
+  const uint32_t j = blockIdx.x / nparts, part = blockIdx.x % nparts, t = threadIdx.x, lane = t & 63;
   if (t < PIP_COARSE) cnt[t] = 0;
   __syncthreads();
   const int16_t* dg = digits + (size_t)j * n;
@@ -151,81 +173,121 @@ __global__ void __launch_bounds__(1024) k_pip_part1(const int16_t* __restrict__ 
     }
   }
   __syncthreads();
-  if (t < PIP_COARSE) {
-    const uint32_t c = cnt[t];
-    if (c) cnt[t] = atomicAdd(&cur1[j * PIP_COARSE + t], c);
+  uint32_t c = 0, incl = 0;
+  if (t < PIP_COARSE) {                                       // waves 0..3, whole
+    c = cnt[t];
+    incl = pip_wave_incl_scan(c, lane);
+    if (lane == 63) wsum[t >> 6] = incl;
   }
   __syncthreads();
-  uint32_t* oi = l1_idx + (size_t)j * n;
-  uint8_t* ok = l1_key + (size_t)j * n;
+  if (t < PIP_COARSE) {
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < (t >> 6); w++) base += wsum[w];
+    cnt[t] = base + incl - c;
+    gb[t] = c ? atomicAdd(&cur1[j * PIP_COARSE + t], c) : 0u;
+  }
+  __syncthreads();
   SPP_UNROLL for (uint32_t k = 0; k < PIP_PART / 1024; k++) {
     if (kr[k] != 0xffffffffu) {
-      const uint32_t b = kr[k] >> 16, dest = cnt[b >> PIP_FINE_BITS] + (kr[k] & 0xffffu);
-      if constexpr (PACKED) oi[dest] = ent[k] | ((b & (PIP_FINE - 1)) << 24);
+      const uint32_t b = kr[k] >> 16, s = cnt[b >> PIP_FINE_BITS] + (kr[k] & 0xffffu);
+      if constexpr (PACKED) stage[s] = ent[k] | ((b & (PIP_FINE - 1)) << 24);
       else {
-        oi[dest] = ent[k];
-        ok[dest] = (uint8_t)(b & (PIP_FINE - 1));
+        stage[s] = ent[k];
+        stagek[s] = (uint8_t)(b & (PIP_FINE - 1));
       }
     }
   }
+  __syncthreads();
+  const uint32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  uint32_t* oi = l1_idx + (size_t)j * n;
+  uint8_t* ok = l1_key + (size_t)j * n;
+  for (uint32_t s = t; s < total; s += 1024) {
+    const uint32_t bin = pip_slot_of(cnt, PIP_COARSE, s), dest = gb[bin] + (s - cnt[bin]);
+    oi[dest] = stage[s];
+    if constexpr (!PACKED) ok[dest] = stagek[s];
+  }
 }
 
-// Level 2: workgroup per (window, piece of PIP_PART entries of the level-1 list).  The piece lies in coarse bins c_lo..c_hi
-// (one or two for uniform scalars); counter (c - c_lo) * 128 + fine key, same three phases, cursor per bucket.
+// Level 2: workgroup per (window, piece of PIP_PART2 entries of the level-1 list).  The piece lies in coarse bins c_lo..c_hi
+// (one or two for uniform scalars; a skewed window may put many small bins into one piece: the piece is then taken in sub-pieces
+// of at most 16 coarse bins = PIP_R2 counters); counter (c - c0) * 128 + fine key, the same four phases, cursor per bucket.
+static constexpr uint32_t PIP_PART2 = 8192, PIP_R2 = 2048, PIP_R2_PER = PIP_R2 / 1024;    // 49 KB of LDS: two workgroups per CU
 template <bool PACKED>
 __global__ void __launch_bounds__(1024) k_pip_part2(uint32_t n, uint32_t nparts, const uint32_t* __restrict__ offs,
                                                     const uint32_t* __restrict__ hist, const uint32_t* __restrict__ l1_idx,
                                                     const uint8_t* __restrict__ l1_key, uint32_t* __restrict__ cur2,
                                                     uint32_t* __restrict__ sorted) {
-  __shared__ uint32_t cnt[PIP_B];                             // 128 KB; only (c_hi - c_lo + 1) * 128 words are touched
+  __shared__ uint32_t cnt[PIP_R2];                            // counts, then the local exclusive prefix
+  __shared__ uint32_t gb[PIP_R2];                             // where the bucket's run starts in the window's list
+  __shared__ uint32_t stage[PIP_PART2];                       // 32 KB
   __shared__ uint32_t cstart[PIP_COARSE + 1];
-  const uint32_t j = blockIdx.x / nparts, part = blockIdx.x % nparts, t = threadIdx.x;
+  __shared__ uint32_t wsum[16];
+  const uint32_t j = blockIdx.x / nparts, part = blockIdx.x % nparts, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const uint32_t* o = offs + j * PIP_B;
   const uint32_t total = o[PIP_B - 1] + hist[j * PIP_B + PIP_B - 1];
-  const uint32_t lo = part * PIP_PART;
+  const uint32_t lo = part * PIP_PART2;
   if (lo >= total) return;                                    // the whole workgroup
-  const uint32_t hi = min(lo + PIP_PART, total);
+  const uint32_t hi = min(lo + PIP_PART2, total);
   if (t < PIP_COARSE) cstart[t] = o[t << PIP_FINE_BITS];
   if (t == PIP_COARSE) cstart[PIP_COARSE] = total;
   __syncthreads();
-  auto bin_of = [&](uint32_t pos) {                           // largest c with cstart[c] <= pos: the (non-empty) bin holding pos
-    uint32_t a = 0, b = PIP_COARSE - 1;
-    while (a < b) {
-      const uint32_t mid = (a + b + 1) >> 1;
-      if (cstart[mid] <= pos) a = mid; else b = mid - 1;
-    }
-    return a;
-  };
-  const uint32_t c_lo = bin_of(lo), c_hi = bin_of(hi - 1), range = (c_hi - c_lo + 1) << PIP_FINE_BITS;
-  for (uint32_t b = t; b < range; b += 1024) cnt[b] = 0;
-  __syncthreads();
+  const uint32_t c_lo = pip_slot_of(cstart, PIP_COARSE, lo), c_hi = pip_slot_of(cstart, PIP_COARSE, hi - 1);
   const uint32_t* li = l1_idx + (size_t)j * n;
   const uint8_t* lk = l1_key + (size_t)j * n;
-  uint32_t ent[PIP_PART / 1024], kr[PIP_PART / 1024];         // entry; counter << 16 | rank
-  SPP_UNROLL for (uint32_t k = 0; k < PIP_PART / 1024; k++) {
-    const uint32_t pos = lo + k * 1024 + t;
-    kr[k] = 0xffffffffu;
-    if (pos < hi) {
-      const uint32_t c = c_lo == c_hi ? c_lo : bin_of(pos);
-      uint32_t en = li[pos], fine;
-      if constexpr (PACKED) {
-        fine = (en >> 24) & (PIP_FINE - 1);
-        en &= 0x80ffffffu;
-      } else fine = lk[pos];
-      const uint32_t kk = ((c - c_lo) << PIP_FINE_BITS) + fine;
-      ent[k] = en;
-      kr[k] = (kk << 16) | atomicAdd(&cnt[kk], 1u);
-    }
-  }
-  __syncthreads();
-  for (uint32_t b = t; b < range; b += 1024) {
-    const uint32_t c = cnt[b];
-    if (c) cnt[b] = atomicAdd(&cur2[j * PIP_B + (c_lo << PIP_FINE_BITS) + b], c);
-  }
-  __syncthreads();
   uint32_t* out = sorted + (size_t)j * n;
-  SPP_UNROLL for (uint32_t k = 0; k < PIP_PART / 1024; k++)
-    if (kr[k] != 0xffffffffu) out[cnt[kr[k] >> 16] + (kr[k] & 0xffffu)] = ent[k];
+  for (uint32_t c0 = c_lo; c0 <= c_hi; c0 += PIP_R2 / PIP_FINE) {
+    const uint32_t c1 = min(c0 + PIP_R2 / PIP_FINE - 1, c_hi);
+    const uint32_t sub_lo = max(lo, cstart[c0]), sub_hi = min(hi, cstart[c1 + 1]);
+    if (sub_lo >= sub_hi) continue;                           // block-uniform
+    const uint32_t range = (c1 - c0 + 1) << PIP_FINE_BITS;
+    for (uint32_t b = t; b < range; b += 1024) cnt[b] = 0;
+    __syncthreads();
+    uint32_t ent[PIP_PART2 / 1024], kr[PIP_PART2 / 1024];       // entry; counter << 16 | rank
+    SPP_UNROLL for (uint32_t k = 0; k < PIP_PART2 / 1024; k++) {
+      const uint32_t pos = sub_lo + k * 1024 + t;
+      kr[k] = 0xffffffffu;
+      if (pos < sub_hi) {
+        const uint32_t c = c0 == c1 ? c0 : pip_slot_of(cstart, PIP_COARSE, pos);
+        uint32_t en = li[pos], fine;
+        if constexpr (PACKED) {
+          fine = (en >> 24) & (PIP_FINE - 1);
+          en &= 0x80ffffffu;
+        } else fine = lk[pos];
+        const uint32_t kk = ((c - c0) << PIP_FINE_BITS) + fine;
+        ent[k] = en;
+        kr[k] = (kk << 16) | atomicAdd(&cnt[kk], 1u);
+      }
+    }
+    __syncthreads();
+    uint32_t loc[PIP_R2_PER], sum = 0;                        // scan: PIP_R2_PER consecutive counters per lane
+    SPP_UNROLL for (uint32_t q = 0; q < PIP_R2_PER; q++) {
+      const uint32_t idx = t * PIP_R2_PER + q;
+      loc[q] = idx < range ? cnt[idx] : 0u;
+      sum += loc[q];
+    }
+    const uint32_t incl = pip_wave_incl_scan(sum, lane);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (uint32_t w = 0; w < wave; w++) run += wsum[w];
+    SPP_UNROLL for (uint32_t q = 0; q < PIP_R2_PER; q++) {
+      const uint32_t idx = t * PIP_R2_PER + q;
+      if (idx < range) {
+        cnt[idx] = run;
+        gb[idx] = loc[q] ? atomicAdd(&cur2[j * PIP_B + (c0 << PIP_FINE_BITS) + idx], loc[q]) : 0u;
+        run += loc[q];
+      }
+    }
+    __syncthreads();
+    SPP_UNROLL for (uint32_t k = 0; k < PIP_PART2 / 1024; k++)
+      if (kr[k] != 0xffffffffu) stage[cnt[kr[k] >> 16] + (kr[k] & 0xffffu)] = ent[k];
+    __syncthreads();
+    for (uint32_t s = t; s < sub_hi - sub_lo; s += 1024) {
+      const uint32_t kk = pip_slot_of(cnt, range, s);
+      out[gb[kk] + (s - cnt[kk])] = stage[s];
+    }
+    __syncthreads();                                          // the next sub-piece reuses cnt / gb / stage
+  }
 }
 
 // Bucket accumulation, robust to skewed digit distributions (real witnesses are mostly small: one window then holds
@@ -234,7 +296,7 @@ __global__ void __launch_bounds__(1024) k_pip_part2(uint32_t n, uint32_t nparts,
 // every bucket boundary.  A bucket that lies inside one segment is written directly; a bucket that spans segments
 // gets one partial per segment it touches -- `tail[s]` from the segment where it starts, `head[s]` from every later
 // one -- and k_pip_fixup adds them up (a handful of additions for uniform scalars, cnt/SEG for a heavy bucket).
-static constexpr uint32_t PIP_SEG = 256;
+static constexpr uint32_t PIP_SEG = 256, PIP_IDX = 16;
 __device__ __forceinline__ uint32_t pip_bucket_of(const uint32_t* __restrict__ offs, uint32_t pos) {
   // largest b with offs[b] <= pos (offs is non-decreasing; empty buckets repeat the same offset)
   uint32_t lo = 0, hi = PIP_B - 1;
@@ -278,16 +340,29 @@ __global__ void __launch_bounds__(256) k_pip_segments(const Affine<F>* __restric
     else buckets[(size_t)j * PIP_B + b] = r;
   };
   // software pipeline: the (randomly placed, 64 B) base of entry k + 1 is requested before the ~2.3 K
-  // instructions of the addition of entry k, so the HBM round trip of the gather hides behind arithmetic of the same lane
-  // (the index of entry k + 2 is requested in the same step: the gather of k + 1 never waits for its own address)
-  uint32_t e = seg[pos], e_ahead = pos + 1 < end ? seg[pos + 1] : 0u;
+  // instructions of the addition of entry k, so the HBM round trip of the gather hides behind arithmetic of the same lane.
+  // The lane's list entries come through LDS sixteen at a time (64 B, one sector, fetched once): a lane reading one 4-byte
+  // entry per addition found its sector evicted between two reads -- the gathers sweep the L2 in tens of microseconds -- and
+  // the list cost 4.5x its size in fabric requests (profiles/round3_pippenger_pmc_hbm.json).
+  __shared__ uint32_t sidx[PIP_IDX][256];
+  const uint32_t tid = threadIdx.x;
+  auto refill = [&](uint32_t k0) {                         // entries k0 .. k0 + 15 of this lane's segment, column tid
+    uint32_t v[PIP_IDX];
+    SPP_UNROLL for (uint32_t q = 0; q < PIP_IDX; q++) v[q] = k0 + q < end ? seg[k0 + q] : 0u;
+    SPP_UNROLL for (uint32_t q = 0; q < PIP_IDX; q++) sidx[q][tid] = v[q];
+  };
+  refill(pos);
+  uint32_t e = sidx[0][tid];
   Affine<F> p = bases[e & 0x7fffffffu];
   for (uint32_t k = pos; k < end; k++) {
     const uint32_t e_cur = e;
     const Affine<F> p_cur = p;
-    e = e_ahead;
-    if (k + 1 < end) p = bases[e & 0x7fffffffu];
-    if (k + 2 < end) e_ahead = seg[k + 2];
+    if (k + 1 < end) {
+      const uint32_t r = (k + 1 - pos) & (PIP_IDX - 1);
+      if (r == 0) refill(k + 1);
+      e = sidx[r][tid];
+      p = bases[e & 0x7fffffffu];
+    }
     if (k == bend) {                                       // next non-empty bucket starts here
       flush(false);
       acc = Acc::infinity();
@@ -436,7 +511,7 @@ uint32_t pippenger_windows() { return PIP_W; }
 template <class F>
 static void launch_pippenger(hipStream_t st, const Affine<F>* bases, const Fr* scalars, uint32_t n, void* workspace, XYZZ<F>** out_windows,
                              hipEvent_t ev0, hipEvent_t ev1) {
-  const uint32_t ntiles = pip_ntiles(n), nparts = n ? (n + PIP_PART - 1) / PIP_PART : 1;
+  const uint32_t ntiles = pip_ntiles(n), nparts = n ? (n + PIP_PART - 1) / PIP_PART : 1, nparts2 = n ? (n + PIP_PART2 - 1) / PIP_PART2 : 1;
   uint32_t* hist = (uint32_t*)workspace;
   uint32_t* offs = hist + PIP_W * PIP_B;
   uint32_t* cur2 = offs + PIP_W * PIP_B;
@@ -461,10 +536,10 @@ static void launch_pippenger(hipStream_t st, const Affine<F>* bases, const Fr* s
   hipLaunchKernelGGL(k_pip_cursors, dim3(PIP_W * PIP_B / 256), dim3(256), 0, st, offs, cur1, cur2);
   if (n <= (1u << 24) && !getenv("SPP_PIP_UNPACKED")) {     // (the switch lets the tests run the large-n form on small inputs)
     hipLaunchKernelGGL(k_pip_part1<true>, dim3(PIP_W * nparts), dim3(1024), 0, st, digits, n, nparts, cur1, l1_idx, l1_key);
-    hipLaunchKernelGGL(k_pip_part2<true>, dim3(PIP_W * nparts), dim3(1024), 0, st, n, nparts, offs, hist, l1_idx, l1_key, cur2, sorted);
+    hipLaunchKernelGGL(k_pip_part2<true>, dim3(PIP_W * nparts2), dim3(1024), 0, st, n, nparts2, offs, hist, l1_idx, l1_key, cur2, sorted);
   } else {
     hipLaunchKernelGGL(k_pip_part1<false>, dim3(PIP_W * nparts), dim3(1024), 0, st, digits, n, nparts, cur1, l1_idx, l1_key);
-    hipLaunchKernelGGL(k_pip_part2<false>, dim3(PIP_W * nparts), dim3(1024), 0, st, n, nparts, offs, hist, l1_idx, l1_key, cur2, sorted);
+    hipLaunchKernelGGL(k_pip_part2<false>, dim3(PIP_W * nparts2), dim3(1024), 0, st, n, nparts2, offs, hist, l1_idx, l1_key, cur2, sorted);
   }
   if (ev0) hipEventRecord(ev0, st);
   hipLaunchKernelGGL(k_pip_segments<F>, dim3((PIP_W * nseg + 255) / 256), dim3(256), 0, st, bases, n, nseg, offs, hist, sorted, buckets,

@@ -975,6 +975,22 @@ __global__ void __launch_bounds__(256) k_spmv_check(DevCircuit dc, const Fr* __r
   }
   if (bad) atomicOr(&status[p], 1u);
 }
+// long rows (DevCircuit::lg_rows): workgroup = 64 proofs x 16 term classes; lane (class s, proof p) sums the terms s, s + 16, ...
+// of the row with coalesced witness reads, the 16 partial sums meet in LDS.  blockIdx.y = long row.
+static constexpr uint32_t LONG_G = 16;
+__global__ void __launch_bounds__(1024) k_spmv_long_rows(DevCircuit dc, const Fr* __restrict__ W, Fr* __restrict__ abc, uint32_t n, uint32_t P) {
+  __shared__ Fr part[LONG_G][64];
+  const uint32_t lane = threadIdx.x & 63, sub = threadIdx.x >> 6, p = blockIdx.x * 64 + lane;
+  const uint32_t code = dc.lg_rows[blockIdx.y], mi = code >> 30, k = code & 0x3fffffffu;
+  const DevSparse& m = mi == 0 ? dc.A : mi == 1 ? dc.B : dc.C;
+  part[sub][lane] = p < P ? dev_row_dot_wide(m, dc.coeffs, k, W, P, p, sub, LONG_G) : Fr::zero();
+  __syncthreads();
+  if (sub != 0 || p >= P) return;
+  Fr acc = part[0][lane];
+  SPP_UNROLL for (uint32_t q = 1; q < LONG_G; q++) acc = acc + part[q][lane];
+  abc[(uint64_t)mi * n * P + (uint64_t)k * P + p] = acc;
+}
+
 // small batches: SPMV_G lanes -> (constraint k, proof p), each lane takes every SPMV_G-th term of the three rows and the partial
 // sums meet through wave shuffles.  The run kernel above saves the repeated B evaluations of a batch, but a run of thousands of
 // constraints, or one row of 6 720 terms (the lookup sum of the audit circuit), is one lane's serial work there: 4.6 ms for a
@@ -1024,8 +1040,9 @@ void launch_spmv_check(hipStream_t st, DevCircuit dc, const Fr* W, Fr* abc, uint
     hipLaunchKernelGGL(k_small_extract, dim3((uint32_t)((l1 + 255) / 256)), dim3(256), 0, st, dc, W, small, P, status);
     hipLaunchKernelGGL(k_spmv_small_rows, dim3((uint32_t)((l2 + 255) / 256)), dim3(256), 0, st, dc, small, W, abc, n, P);
   } else {
-    dc.row_small = nullptr;
+    dc.row_small = dc.row_long;
   }
+  if (dc.lg_n) hipLaunchKernelGGL(k_spmv_long_rows, dim3((P + 63) / 64, dc.lg_n), dim3(1024), 0, st, dc, W, abc, n, P);
   const uint64_t lanes = (uint64_t)(dc.n_runs + (n - dc.n_constraints)) * P;
   hipLaunchKernelGGL(k_spmv_check, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, st, dc, W, abc, n, P, status);
 }

@@ -492,7 +492,7 @@ static int coop_plan(spp_circuit* c) {
 // profiles/round2_audit_b2048_pmc_hbm.json); as integers over a 13 MB array they take well under a millisecond.
 // SPP_NO_SMALL_ROWS=1 (diagnostic): off.
 static constexpr uint32_t SMALL_ROW_MIN = 64, SMALL_ROW_REST = 32;
-static int small_rows_plan(spp_circuit* c) {
+static int small_rows_plan(spp_circuit* c, std::vector<uint8_t>& flags_out) {
   const Circuit& circ = c->circ;
   c->dc.sm_nrows = 0;
   c->dc.sm_nslots = 0;
@@ -574,17 +574,58 @@ static int small_rows_plan(spp_circuit* c) {
   // a run have identical B rows, so they qualify together
   uint32_t *d_w, *d_rp, *d_sl, *d_ro, *d_xp, *d_xw, *d_xc;
   int32_t *d_lo, *d_co;
-  uint8_t* d_fl;
   int e;
   if (rest_wire.empty()) { rest_wire.push_back(0); rest_coeff.push_back(0); }   // never read: keeps the uploads non-empty
   if ((e = own_upload(c, &d_w, wires)) || (e = own_upload(c, &d_lo, lo)) || (e = own_upload(c, &d_rp, rowptr)) || (e = own_upload(c, &d_sl, slots)) ||
-      (e = own_upload(c, &d_co, coefs)) || (e = own_upload(c, &d_ro, row_out)) || (e = own_upload(c, &d_fl, flags)) ||
+      (e = own_upload(c, &d_co, coefs)) || (e = own_upload(c, &d_ro, row_out)) ||
       (e = own_upload(c, &d_xp, rest_ptr)) || (e = own_upload(c, &d_xw, rest_wire)) || (e = own_upload(c, &d_xc, rest_coeff)))
     return e;
   c->dc.sm_rest_ptr = d_xp; c->dc.sm_rest_wire = d_xw; c->dc.sm_rest_coeff = d_xc;
   c->dc.sm_wires = d_w; c->dc.sm_lo = d_lo; c->dc.sm_nslots = (uint32_t)wires.size();
   c->dc.sm_rowptr = d_rp; c->dc.sm_slot = d_sl; c->dc.sm_coef = d_co; c->dc.sm_row_out = d_ro; c->dc.sm_nrows = (uint32_t)row_out.size();
-  c->dc.row_small = d_fl;
+  flags_out = flags;
+  return 0;
+}
+
+// the "already in abc" bits of k_spmv_check: small rows (above) and long rows (DevCircuit::lg_rows)
+static constexpr uint32_t LONG_ROW_MIN = 512;
+static int row_paths_plan(spp_circuit* c) {
+  const Circuit& circ = c->circ;
+  std::vector<uint8_t> small_flags;
+  if (int e = small_rows_plan(c, small_flags)) return e;
+  const uint32_t nc = std::max<uint32_t>(circ.n_constraints, 1);
+  if (small_flags.empty()) small_flags.assign(nc, 0);
+  std::vector<uint8_t> long_flags(nc, 0);
+  std::vector<uint32_t> lg;
+  c->dc.lg_n = 0;
+  c->dc.lg_rows = nullptr;
+  c->dc.row_long = nullptr;
+  if (!getenv("SPP_NO_LONG_ROWS")) {
+    const Sparse* mats[3] = {&circ.A, &circ.B, &circ.C};
+    for (uint32_t mi = 0; mi < 3; mi++)
+      for (uint32_t k = 0; k < circ.n_constraints; k++)
+        if (mats[mi]->rowptr[k + 1] - mats[mi]->rowptr[k] > LONG_ROW_MIN && !(small_flags[k] & (1u << mi))) {
+          lg.push_back((mi << 30) | k);
+          long_flags[k] |= (uint8_t)(1u << mi);
+        }
+  }
+  int e;
+  if (!lg.empty()) {
+    uint32_t* d_lg;
+    uint8_t* d_lf;
+    if ((e = own_upload(c, &d_lg, lg)) || (e = own_upload(c, &d_lf, long_flags))) return e;
+    c->dc.lg_rows = d_lg;
+    c->dc.lg_n = (uint32_t)lg.size();
+    c->dc.row_long = d_lf;
+  }
+  if (c->dc.sm_nrows) {
+    for (uint32_t k = 0; k < nc; k++) small_flags[k] |= long_flags[k];
+    uint8_t* d_fl;
+    if ((e = own_upload(c, &d_fl, small_flags))) return e;
+    c->dc.row_small = d_fl;
+  } else {
+    c->dc.row_small = c->dc.row_long;
+  }
   return 0;
 }
 
@@ -1164,7 +1205,7 @@ static int load_circuit_impl(spp_ctx* ctx, const char* circuit_path, const char*
   c->generic_solver = generic_ops;
   if (generic_ops) c->no_coop = true;
   else if (int e = coop_plan(c)) return e;
-  if (int e = small_rows_plan(c)) return e;
+  if (int e = row_paths_plan(c)) return e;
 
   // ---- NTT tables ----
   {
