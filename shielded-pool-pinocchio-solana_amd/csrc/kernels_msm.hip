@@ -61,9 +61,16 @@ MsmPlan msm_plan(uint32_t N, uint32_t P, uint32_t c, uint32_t Wt, uint32_t occ) 
     maxS = std::max<uint64_t>((N + 3) / 4, 1);
     const double cap = 1024.0 * (occ ? occ : 1);                       // resident waves
     const double wps = (double)lanes_per_slice / 64.0;                  // waves per slice (all passes)
-    // small batches wait on every dependent launch for SIMDs to come free: shorter waves (three times as many rounds) let the
-    // short kernels of the other batches in flight start sooner (128-proof audit batches, four in flight: +2 %)
-    const uint32_t rnd = P <= 256 ? 3 * rounds : rounds;
+    // small batches (P <= 256): TWO rounds.  Round 3's first guess was the opposite -- three times as many rounds, so that the short
+    // kernels of the other batches in flight find free SIMDs sooner -- but every slice ends in a 128-byte partial sum per lane that
+    // the folds read again: with the radix-8 folds and four batches in flight, 128-proof audit batches measure 25.0 ms per step
+    // at 12 rounds, 24.5 at 4, 23.6 at 2, 24.1 at 1 (one box, profiles/rehearsal_probe.py; SPP_MSM_WAVES_SMALL overrides)
+    static const uint32_t rounds_small = [] {
+      const char* e = getenv("SPP_MSM_WAVES_SMALL");
+      const int v = e ? atoi(e) : 2;
+      return (uint32_t)(v >= 1 && v <= 64 ? v : 2);
+    }();
+    const uint32_t rnd = P <= 256 ? rounds_small : rounds;
     const uint64_t S0 = std::max<uint64_t>(1, (uint64_t)(rnd * cap / wps + 0.5));
     uint64_t lo = std::max<uint64_t>(1, S0 - S0 / 4), hi = S0 + S0 / 2;
     lo = std::min(lo, maxS);
