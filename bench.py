@@ -426,13 +426,13 @@ def main():
         h.set_serial(False)
 
         # ---- BASELINE.json configs[2] rehearsed on ONE GPU: 1 024 audit proofs over 8 GPUs are 128 per rank and step.  The same
-        # handle proves the first 128 rows of this rank's batch, pipelined exactly like the headline (libspp keeps up to four
+        # handle proves the first 128 rows of this rank's batch, pipelined exactly like the headline (libspp keeps up to six
         # such batches in flight); its rate beside the 2 048-proof rate is what one rank of a strong-scaling run delivers.
         def pipelined_rate(Bs, n_steps, n_warm):
             outs = [(torch.zeros(Bs * 388, dtype=torch.uint8, device=dev), torch.zeros(Bs * h.pw_len, dtype=torch.uint8, device=dev),
-                     torch.zeros(Bs, dtype=torch.int32, device=dev)) for _ in range(4)]
+                     torch.zeros(Bs, dtype=torch.int32, device=dev)) for _ in range(8)]   # more than libspp keeps in flight (6)
             def go(i):
-                pr, pw, st_ = outs[i & 3]
+                pr, pw, st_ = outs[i & 7]
                 h.prove_batch_device(Bs, inp.data_ptr(), rs.data_ptr(), pr.data_ptr(), pw.data_ptr(), st_.data_ptr())
             for i in range(n_warm):
                 go(i)

@@ -27,9 +27,9 @@ rng = random.Random(1)
 R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 rs = torch.frombuffer(bytearray(b"".join(rng.randrange(1, R).to_bytes(32, "big") + rng.randrange(1, R).to_bytes(32, "big") for _ in range(B))), dtype=torch.uint8).to(dev)
 outs = [(torch.zeros(B * 388, dtype=torch.uint8, device=dev), torch.zeros(B * h.pw_len, dtype=torch.uint8, device=dev),
-         torch.zeros(B, dtype=torch.int32, device=dev)) for _ in range(4)]
+         torch.zeros(B, dtype=torch.int32, device=dev)) for _ in range(8)]
 def go(i):
-    pr, pw, st_ = outs[i & 3]
+    pr, pw, st_ = outs[i & 7]
     h.prove_batch_device(B, inp.data_ptr(), rs.data_ptr(), pr.data_ptr(), pw.data_ptr(), st_.data_ptr())
 for i in range(8):
     go(i)

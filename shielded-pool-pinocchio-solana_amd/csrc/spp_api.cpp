@@ -1692,7 +1692,7 @@ static int ws_depth(size_t count, bool generic_solver = false) {
     return v >= 1 && v <= SPP_NWS ? v : 0;
   }();
   if (forced) return forced;
-  return count <= 256 ? 4 : (count <= 768 || generic_solver) ? 3 : 2;
+  return count <= 256 ? 6 : count <= 768 ? 4 : generic_solver ? 3 : 2;
 }
 extern "C" int spp_prove_batch_device(spp_circuit* c, size_t count, const void* d_inputs, const void* d_rs, void* d_proofs, void* d_pws,
                                       void* d_status) {
@@ -1703,7 +1703,8 @@ extern "C" int spp_prove_batch_device(spp_circuit* c, size_t count, const void* 
   HIP_TRY(hipSetDevice(c->ctx->device));
   // Batches in flight: two for big batches (more adds nothing once the latency-bound phases are covered: DESIGN 8.3); small
   // batches -- 128 proofs are one of 8 ranks' share of BASELINE.json configs[2] -- spend a larger part of their time in
-  // latency-bound kernels (11 ms of sponge chain in the solver, the Horner combines), so up to four take turns.
+  // latency-bound kernels (11 ms of sponge chain in the solver, the Horner combines), so up to six take turns
+  // (128-proof audit batches, ms per step on one box: 25.3 with four in flight, 23.3 with five, 23.1 with six).
   const int depth = ws_depth(count, c->generic_solver);
   if (c->next_ws >= depth) c->next_ws = 0;
   const int wi = c->next_ws, wo = (wi + 1) % depth;

@@ -128,12 +128,12 @@ inline hipError_t dev_upload(T** dst, const std::vector<T>& src) {
 // -----------------------------------------------------------------------------------------------------
 // context / circuit objects
 // -----------------------------------------------------------------------------------------------------
-static constexpr int SPP_NWS = 4;   // batch workspaces / proving streams per circuit (big batches use two)
+static constexpr int SPP_NWS = 6;   // batch workspaces / proving streams per circuit (big batches use two)
 struct spp_ctx {
   int device;
   hipStream_t stream;        // setup / table construction
   hipStream_t pstream[SPP_NWS];   // proving: consecutive batches take the streams in turn, so the (latency-bound, few-wave)
-                                  // witness solver of batch k+1 overlaps the MSMs of batch k; small batches use up to four
+                                  // witness solver of batch k+1 overlaps the MSMs of batch k; small batches use up to six
   std::mutex mu;
   // lazily created constants of the stand-alone witness kernels
   bool consts_ready = false;

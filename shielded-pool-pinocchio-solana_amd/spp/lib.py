@@ -36,7 +36,7 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise ImportError("libspp.so not found at %s -- build it with __graft_entry__.build() "
                           "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
-    # libspp keeps up to four batches in flight, each on a proving stream plus a side stream for the G2 sum: with the HIP
+    # libspp keeps up to six batches in flight, each on a proving stream plus a side stream for the G2 sum: with the HIP
     # runtime's default of 4 hardware queues per device unrelated streams end up sharing a queue and run one after the other
     # (128-proof batches, four in flight: 3 755 proofs/s with 4 queues, 4 554 with 8).  Read when the runtime initialises.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")

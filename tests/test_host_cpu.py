@@ -420,7 +420,7 @@ def test_committed_bench_line_follows_the_contract():
     field of the driver's contract, the roofline object and the CPU baseline, with consistent arithmetic; the headline is the
     audit circuit on a batch of distinct witnesses, and every extra leg ran at least 10 timed steps."""
     import json
-    j = json.load(open(os.path.join(ROOT, "profiles", "round2_bench_default_run.json")))
+    j = json.load(open(os.path.join(ROOT, "profiles", "round3_bench_default_run.json")))
     for k, t in (("metric", str), ("value", (int, float)), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                  ("ms_per_step", (int, float)), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict)):
         assert isinstance(j[k], t), k
@@ -432,7 +432,7 @@ def test_committed_bench_line_follows_the_contract():
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5
     assert abs(r["achieved"] - r["alg_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 0.01
-    assert r["launches_per_step"] * r["avg_launch_ms"] <= j["ms_per_step"]          # the dominant kernel's launches fit inside a step
+    assert r["launches_per_step"] == 4 and r["launches_per_step"] * r["avg_launch_ms"] <= j["ms_per_step"]   # A, B1, K, Z walks fit inside a step
     assert r["traffic"] is None or r["traffic"] > r["alg_bytes_per_launch"]
     cb = j["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == j["unit"] and cb["sample"]
@@ -440,6 +440,10 @@ def test_committed_bench_line_follows_the_contract():
         assert j[leg]["steps"] >= 10 and j[leg]["config"]["n_distinct_witnesses"] == j[leg]["config"]["batch_per_gpu"], leg
     assert j["withdraw_at_reference_r1cs_size"]["config"]["n_constraints"] == 12452
     assert j["rlwe_witness_2p16"]["iters"] >= 10 and j["msm_g1_2p24"]["iters"] >= 10
+    # round 3's legs: the per-rank shard of configs[2], the clock at the secrets, both circuits resident, the reference's own R1CS
+    assert j["strong_scaling_rank_rehearsal"]["batch"] == 128 and j["strong_scaling_rank_rehearsal"]["steps"] >= 10
+    assert j["audit_end_to_end_from_secrets"]["proof_bytes_equal_the_proofs_from_rows"] is True
+    assert j["audit_plus_withdraw_coresident"]["steps"] >= 10 and j["withdraw_reference_gnark_r1cs"]["config"]["n_inputs"] == 26
     # the PMC summary the line's `traffic` comes from describes the same workload
     pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_latest.json")))
     assert pmc["circuit"] == "audit" and pmc["batch"] == 2048 and pmc["n_distinct_witnesses"] == 2048
