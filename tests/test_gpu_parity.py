@@ -610,6 +610,41 @@ def test_audit_proof_bytes_match_oracle_and_verify(ctx, audit_artifacts, rlwe_pk
         h.close()
 
 
+def test_matrix_evaluation_paths_agree(ctx, audit_artifacts, rlwe_pk, monkeypatch):
+    """<A,w>, <B,w>, <C,w> three ways on a 70-proof audit batch (the run kernel's regime): every row in field arithmetic on one lane
+    per (run, proof); the 1 088 quotient equations as integer sums (small rows); the 6 720-term lookup row on 16 lanes per proof
+    (long rows).  The switches take the paths out one by one; the proofs must not change, and a bad row is refused on every path."""
+    from oracle import native
+    rows = _audit_rows(rlwe_pk, 3)
+    batch = [rows[i % 3] for i in range(70)]
+    rs = [(5 + i, 900 + 7 * i) for i in range(70)]
+    bad = list(rows[1]); bad[1] += 1
+    got = {}
+    for name, env in (("all", {}), ("no_small", {"SPP_NO_SMALL_ROWS": "1"}), ("no_long", {"SPP_NO_LONG_ROWS": "1"}),
+                      ("neither", {"SPP_NO_SMALL_ROWS": "1", "SPP_NO_LONG_ROWS": "1"})):
+        for k in ("SPP_NO_SMALL_ROWS", "SPP_NO_LONG_ROWS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        h = ctx.load_circuit(audit_artifacts["sppc"], audit_artifacts["pk"], 6)
+        try:
+            assert (h.small_rows()[0] == 1088) == ("SPP_NO_SMALL_ROWS" not in env)
+            proofs, pws, status = h.prove_batch(batch, rs)
+            assert status == [0] * 70, name
+            got[name] = (proofs, pws)
+            _, _, st = h.prove_batch([batch[i] if i != 66 else bad for i in range(70)], rs)
+            assert st == [0] * 66 + [-4] + [0] * 3, name
+        finally:
+            h.close()
+    for k in ("SPP_NO_SMALL_ROWS", "SPP_NO_LONG_ROWS"):
+        monkeypatch.delenv(k, raising=False)
+    assert got["all"] == got["no_small"] == got["no_long"] == got["neither"]
+    orc = native.Prover(audit_artifacts["sppc"], audit_artifacts["pk"])
+    for i in (0, 64, 69):
+        rc, proof, pw = orc.prove(batch[i], *rs[i])
+        assert rc == 0 and got["all"][0][i] == proof and got["all"][1][i] == pw, i
+
+
 def test_compute_h_forms_agree_with_the_oracle(ctx, withdraw_artifacts, audit_artifacts, withdraw_kat, rlwe_pk, monkeypatch):
     """computeH three ways ("computeH in product form"): gnark's seven transforms (SPP_H_MODE=0: h coefficients
     against pk.G1.Z, groth16/bn254/prove.go computeH), six (H bases moved to the evaluation basis on 5*H) and four (the default: h as
