@@ -15,6 +15,9 @@
 // of a scalar become 16 passes over the same table whose sums are put together by Horner (k_msm_horner); with
 // explicit small windows every window has its own row and there is a single pass.  Work is split over passes and
 // slices of the base range to fill 256 CUs; the slice sums of every (pass, proof) are folded pairwise.
+// This file is compiled TWICE: as it is (every non-template function and the G1 instantiations, with the scheduler strategy
+// max-ilp: the G1 walk is 2 % faster for it, 247 registers, still two waves per SIMD) and through kernels_msm_g2.hip with
+// SPP_MSM_TU_G2 defined (the G2 instantiations alone, default scheduler: max-ilp makes the 512-register G2 walk spill and 4 % slower).
 #include <hip/hip_ext.h>
 #include "kernels.hpp"
 #include <algorithm>
@@ -28,6 +31,7 @@
 
 namespace spp {
 
+#ifndef SPP_MSM_TU_G2
 uint32_t msm_windows(uint32_t c) { return (254 + c - 1) / c; }
 
 // Lane layout of one launch (see kernels.hpp, MsmPlan).  Big batches: the chip holds 1024 SIMDs x `occ` waves of this kernel at
@@ -89,6 +93,7 @@ MsmPlan msm_plan(uint32_t N, uint32_t P, uint32_t c, uint32_t Wt, uint32_t occ) 
   return pl;
 }
 
+#endif  // SPP_MSM_TU_G2
 // ----------------------------------------------------------------------------------------------------
 // table construction: one lane per (base, window) row.
 // Table layout: rows are grouped in blocks of 64; entry d of row `row` lives at ((row/64)*E + d)*64 + row%64, so the
@@ -138,6 +143,7 @@ __global__ void __launch_bounds__(64) k_build_table(const Affine<F>* __restrict_
   }
 }
 
+#ifndef SPP_MSM_TU_G2
 // number of table elements (points) for N bases with Wt window rows each, including the padding of the last 64-row block
 size_t msm_table_elems(uint32_t N, uint32_t c, uint32_t Wt) {
   if (Wt == 0 || Wt > msm_windows(c)) Wt = msm_windows(c);
@@ -145,6 +151,7 @@ size_t msm_table_elems(uint32_t N, uint32_t c, uint32_t Wt) {
   return ((rows + 63) / 64) * 64 * ((size_t)1 << (c - 1));
 }
 
+#endif  // SPP_MSM_TU_G2
 template <class F>
 void launch_build_table(hipStream_t st, const Affine<F>* bases, uint32_t N, uint32_t c, uint32_t Wt, uint32_t row0, uint32_t nrows,
                         Affine<F>* table, XYZZ<F>* tmp, F* tmp_pre) {
@@ -154,10 +161,14 @@ void launch_build_table(hipStream_t st, const Affine<F>* bases, uint32_t N, uint
   const uint32_t R = (W + Wt - 1) / Wt;   // row m of a base holds the multiples of 2^(c*R*m) * Base (pass rho takes windows rho + R*m)
   hipLaunchKernelGGL(k_build_table<F>, dim3((nrows + 63) / 64), dim3(64), 0, st, bases, N, c, Wt, c * R, row0, nrows, table, tmp, tmp_pre);
 }
+#ifndef SPP_MSM_TU_G2
 template void launch_build_table<Fq>(hipStream_t, const Affine<Fq>*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, Affine<Fq>*,
                                      XYZZ<Fq>*, Fq*);
+#endif
+#ifdef SPP_MSM_TU_G2
 template void launch_build_table<Fq2>(hipStream_t, const Affine<Fq2>*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, Affine<Fq2>*,
                                       XYZZ<Fq2>*, Fq2*);
+#endif
 
 // ----------------------------------------------------------------------------------------------------
 // signed-window recoding helpers (scalar in canonical limbs, magnitude < 2^253 after sign folding)
@@ -209,6 +220,7 @@ struct Recoder {
 // base, proof), coalesced, with no recoder state in registers and no carry chain between windows: any window can be
 // processed by any lane, which is what the window passes below need.
 // ----------------------------------------------------------------------------------------------------
+#ifndef SPP_MSM_TU_G2
 __global__ void __launch_bounds__(256) k_msm_digits(const uint32_t* __restrict__ rows, const Fr* __restrict__ scalars,
                                                     int16_t* __restrict__ dig, uint32_t N, uint32_t P, uint32_t Pp, uint32_t c, uint32_t W) {
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -250,6 +262,7 @@ size_t msm_digit_elems(uint32_t N, uint32_t P, uint32_t c) {
   return (size_t)msm_windows(c) * N * Pp;
 }
 
+#endif  // SPP_MSM_TU_G2
 // ----------------------------------------------------------------------------------------------------
 // MSM accumulate over the digit planes.
 //
@@ -557,14 +570,26 @@ void launch_msm_reduce(hipStream_t st, XYZZ<F>* partial, XYZZ<F>* out, uint32_t 
   fs.c[0] = c;
   launch_msm_reduce_multi<F>(st, fs, 1, P);
 }
+#ifndef SPP_MSM_TU_G2
 template void launch_msm_reduce_multi<Fq>(hipStream_t, MsmFoldSets<Fq>, uint32_t, uint32_t);
+#endif
+#ifdef SPP_MSM_TU_G2
 template void launch_msm_reduce_multi<Fq2>(hipStream_t, MsmFoldSets<Fq2>, uint32_t, uint32_t);
+#endif
+#ifndef SPP_MSM_TU_G2
 template void launch_msm_accumulate<Fq>(hipStream_t, const Affine<Fq>*, const int16_t*, XYZZ<Fq>*, uint32_t, uint32_t, uint32_t, const MsmPlan&,
                                         hipEvent_t, hipEvent_t);
+#endif
+#ifdef SPP_MSM_TU_G2
 template void launch_msm_accumulate<Fq2>(hipStream_t, const Affine<Fq2>*, const int16_t*, XYZZ<Fq2>*, uint32_t, uint32_t, uint32_t,
                                          const MsmPlan&, hipEvent_t, hipEvent_t);
+#endif
+#ifndef SPP_MSM_TU_G2
 template void launch_msm_reduce<Fq>(hipStream_t, XYZZ<Fq>*, XYZZ<Fq>*, uint32_t, const MsmPlan&, uint32_t, bool);
+#endif
+#ifdef SPP_MSM_TU_G2
 template void launch_msm_reduce<Fq2>(hipStream_t, XYZZ<Fq2>*, XYZZ<Fq2>*, uint32_t, const MsmPlan&, uint32_t, bool);
+#endif
 
 // ----------------------------------------------------------------------------------------------------
 // The H bases in the evaluation basis (load time).  gnark's computeH ends with an inverse coset transform that turns the
@@ -574,6 +599,7 @@ template void launch_msm_reduce<Fq2>(hipStream_t, XYZZ<Fq2>*, XYZZ<Fq2>*, uint32
 // ~60 ms for n = 2^15 -- and every proof saves its seventh transform (the scalars of the Z walk are the values the pointwise
 // kernel leaves, natural order).  The group element is the same, so are the proof bytes.
 // ----------------------------------------------------------------------------------------------------
+#ifndef SPP_MSM_TU_G2
 __device__ __forceinline__ XYZZ<Fq> g1_scalar_mul(const XYZZ<Fq>& pt, const Fr& k) {
   uint32_t c[8];
   k.to_canonical(c);
@@ -649,6 +675,7 @@ void launch_g1_eval_basis(hipStream_t st, const G1Affine* pts, uint32_t n_pts, u
   hipLaunchKernelGGL(k_g1_to_affine, dim3((n + 63) / 64), dim3(64), 0, st, work, out, n);
 }
 
+#endif  // SPP_MSM_TU_G2
 // ----------------------------------------------------------------------------------------------------
 // setup: out[i] = scalars[i] * G using the window table of the single base G
 // ----------------------------------------------------------------------------------------------------
@@ -682,7 +709,11 @@ void launch_fixed_base_mul(hipStream_t st, const Affine<F>* gen_table, uint32_t 
   if (n == 0) return;
   hipLaunchKernelGGL(k_fixed_base_mul<F>, dim3((n + 63) / 64), dim3(64), 0, st, gen_table, c, msm_windows(c), scalars, n, out);
 }
+#ifndef SPP_MSM_TU_G2
 template void launch_fixed_base_mul<Fq>(hipStream_t, const Affine<Fq>*, uint32_t, const Fr*, uint32_t, Affine<Fq>*, XYZZ<Fq>*);
+#endif
+#ifdef SPP_MSM_TU_G2
 template void launch_fixed_base_mul<Fq2>(hipStream_t, const Affine<Fq2>*, uint32_t, const Fr*, uint32_t, Affine<Fq2>*, XYZZ<Fq2>*);
+#endif
 
 }  // namespace spp
