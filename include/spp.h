@@ -130,8 +130,9 @@ uint64_t spp_circuit_table_bytes(const spp_circuit* c);
 int spp_prove_batch(spp_circuit* c, size_t count, const uint8_t* inputs, const uint8_t* rs, uint8_t* proofs, uint8_t* pws,
                     int32_t* status);
 /* Same with every buffer already resident in HBM (device pointers); asynchronous until spp_sync().
- * Consecutive calls alternate between two HIP streams and two workspaces, so the latency-bound witness solver of
- * batch k+1 overlaps the MSMs of batch k: output buffers must not be shared by two consecutive calls.
+ * Consecutive calls rotate over several HIP streams and workspaces -- two for large batches, four for up to 768 proofs, six for
+ * up to 256 -- so the latency-bound phases of a batch (witness solver, Horner combines) overlap the MSMs of the others: output
+ * buffers must not be shared by calls that may be in flight together (up to six consecutive calls).
  * d_status: uint32 per proof, nonzero = unsatisfied. */
 int spp_prove_batch_device(spp_circuit* c, size_t count, const void* d_inputs, const void* d_rs, void* d_proofs, void* d_pws,
                            void* d_status);
