@@ -25,6 +25,10 @@
 #include <cstdlib>
 #include "f29.hpp"
 
+#ifndef SPP_MSM_WALK_BLOCK
+#define SPP_MSM_WALK_BLOCK 64
+#endif
+static constexpr unsigned MSM_WALK_BLOCK = SPP_MSM_WALK_BLOCK;   // lanes per workgroup of the flat table walk
 #ifndef SPP_G1_GATHER_PIPELINE
 #define SPP_G1_GATHER_PIPELINE 0   // experiment: the one-deep gather pipeline of the G2 walk for G1 as well
 #endif
@@ -323,8 +327,11 @@ struct MsmAcc<Fq2> {
 // throughput layout (Wt = 1): one table row per base, slice sl takes bases sl, sl + Sg, ... (neighbouring wires have similar
 // scalar sizes -- runs of bits, runs of hash states -- so a strided split gives every slice the same mix).  The digits of
 // four bases are fetched ahead of their additions (2 B each, packed into one register pair).
+// One wave per workgroup: a 256-lane workgroup needs FOUR free wave slots of a CU at once, and with 2 slots per SIMD and waves of
+// unequal length (passes over sparse windows are shorter) a finished wave's slot waited for three more -- 1.79 resident waves per SIMD
+// on average where 2 fit.  (The second launch-bound keeps the G1 walk within 256 registers = two waves per SIMD.)
 template <class F>
-__global__ void __launch_bounds__(256) k_msm_flat(const Affine<F>* __restrict__ table, const int16_t* __restrict__ dig,
+__global__ void __launch_bounds__(MSM_WALK_BLOCK, sizeof(F) > sizeof(Fq) ? 1 : 2) k_msm_flat(const Affine<F>* __restrict__ table, const int16_t* __restrict__ dig,
                                                   XYZZ<F>* __restrict__ partial, uint32_t N, uint32_t P, uint32_t Pp, uint32_t c,
                                                   uint32_t R, uint32_t Sg) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -445,7 +452,7 @@ void launch_msm_accumulate(hipStream_t st, const Affine<F>* table, const int16_t
   const uint64_t lanes = (uint64_t)pl.R * pl.Sg * pl.Pp;
   const dim3 grid((uint32_t)((lanes + 255) / 256));
   if (pl.Wt == 1)
-    hipExtLaunchKernelGGL(k_msm_flat<F>, grid, dim3(256), 0, st, ev_start, ev_stop, 0, table, dig, partial, N, P, pl.Pp, c, pl.R, pl.Sg);
+    hipExtLaunchKernelGGL(k_msm_flat<F>, dim3((uint32_t)((lanes + MSM_WALK_BLOCK - 1) / MSM_WALK_BLOCK)), dim3(MSM_WALK_BLOCK), 0, st, ev_start, ev_stop, 0, table, dig, partial, N, P, pl.Pp, c, pl.R, pl.Sg);
   else
     hipExtLaunchKernelGGL(k_msm_rows<F>, grid, dim3(256), 0, st, ev_start, ev_stop, 0, table, dig, partial, N, P, pl.Pp, c, pl.Wt, pl.R,
                           pl.W, pl.Sg, pl.Q, pl.Wq);
