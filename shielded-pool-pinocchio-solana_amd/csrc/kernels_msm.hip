@@ -28,6 +28,7 @@
 #ifndef SPP_MSM_WALK_BLOCK
 #define SPP_MSM_WALK_BLOCK 64
 #endif
+static constexpr unsigned MSM_FOLD_COOP_MAX_BATCH = 8;            // batches up to this size fold their slice sums with 8 lanes per output
 static constexpr unsigned MSM_WALK_BLOCK = SPP_MSM_WALK_BLOCK;   // lanes per workgroup of the flat table walk
 #ifndef SPP_G1_GATHER_PIPELINE
 #define SPP_G1_GATHER_PIPELINE 0   // experiment: the one-deep gather pipeline of the G2 walk for G1 as well
@@ -464,14 +465,43 @@ void launch_msm_accumulate(hipStream_t st, const Affine<F>* table, const int16_t
 // G2 fold with its 256 registers longest: 0.7 ms per level in the trace of pipelined 128-proof batches.)  blockIdx.y = set,
 // blockIdx.z = pass; up to MSM_FOLD_SETS sets share the launches (the five G1 sums of a proof are independent).  A set with
 // one pass leaves the fold in out[p]; with R > 1 passes the pass sums stay in partial[rho * Sg * P + p] for k_msm_horner.
+template <class T>
+__device__ __forceinline__ T msm_shfl_xor(const T& v, int mask) {
+  static_assert(sizeof(T) % 4 == 0, "word-sized");
+  T r;
+  const uint32_t* s = reinterpret_cast<const uint32_t*>(&v);
+  uint32_t* d = reinterpret_cast<uint32_t*>(&r);
+  SPP_UNROLL for (uint32_t i = 0; i < sizeof(T) / 4; i++) d[i] = (uint32_t)__shfl_xor((int)s[i], mask, 64);
+  return r;
+}
+// coop (a handful of proofs, the generateProof latency path): the 8 terms of an output sit on 8 neighbouring lanes and meet in a
+// 3-step shuffle tree instead of one lane adding 7 of them in sequence -- the fold of a single proof's G2 sum is 5 levels deep:
+// 35 dependent G2 additions (0.9 ms, what k_assemble waited for) become 15.
 template <class F>
-__global__ void __launch_bounds__(64) k_msm_fold_multi(MsmFoldSets<F> fs, uint32_t P) {
+__global__ void __launch_bounds__(64) k_msm_fold_multi(MsmFoldSets<F> fs, uint32_t P, uint32_t coop) {
   const uint32_t set = blockIdx.y, rho = blockIdx.z;
   const uint32_t next = fs.half[set], S_cur = fs.cur[set];
-  if (next == 0 || rho >= fs.R[set]) return;   // this set is already folded / has fewer passes
+  if (next == 0 || rho >= fs.R[set]) return;   // this set is already folded / has fewer passes (whole workgroups)
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= next * P) return;
   XYZZ<F>* __restrict__ partial = fs.partial[set] + (size_t)rho * fs.Sg[set] * P;
+  if (coop) {
+    static_assert(MSM_FOLD_RADIX == 8, "three shuffle steps");
+    const uint32_t o = g >> 3, m = g & 7;
+    const bool live = o < next * P;
+    const uint32_t s = live ? o / P : 0, p = live ? o % P : 0, t = s + next * m;
+    XYZZ<F> a = XYZZ<F>::infinity();
+    if (live && t < S_cur) a = partial[(size_t)t * P + p];
+    SPP_UNROLL for (int d = 4; d >= 1; d >>= 1) {               // every lane of the wave reaches the shuffles
+      const XYZZ<F> b = msm_shfl_xor(a, d);
+      a.add(b);
+    }
+    if (live && m == 0) {
+      if (next == 1 && fs.R[set] == 1) fs.out[set][p] = a;
+      else partial[(size_t)s * P + p] = a;
+    }
+    return;
+  }
+  if (g >= next * P) return;
   const uint32_t s = g / P, p = g % P;
   XYZZ<F> a = partial[(size_t)s * P + p];
 #pragma unroll 1
@@ -554,7 +584,9 @@ void launch_msm_reduce_multi(hipStream_t st, MsmFoldSets<F> fs, uint32_t nsets, 
       lanes = std::max<uint64_t>(lanes, (uint64_t)fs.half[i] * P);
     }
     if (lanes == 0) break;
-    hipLaunchKernelGGL(k_msm_fold_multi<F>, dim3((uint32_t)((lanes + 63) / 64), nsets, maxR), dim3(64), 0, st, fs, P);
+    const uint32_t coop = P <= MSM_FOLD_COOP_MAX_BATCH ? 1u : 0u;
+    if (coop) lanes *= MSM_FOLD_RADIX;
+    hipLaunchKernelGGL(k_msm_fold_multi<F>, dim3((uint32_t)((lanes + 63) / 64), nsets, maxR), dim3(64), 0, st, fs, P, coop);
     for (uint32_t i = 0; i < nsets; i++)
       if (!done[i]) {
         cur[i] = fs.half[i];
