@@ -14,7 +14,7 @@ sppc, pkp, vkp = (os.path.join(tmp, name + e) for e in (".sppc", ".pk", ".vk"))
 spp.build_circuit(cid, sppc, aux=(list(pk["a"]) + list(pk["b"])) if cid == 2 else None)
 ctx = spp.Context(0); ctx.setup(sppc, b"\x2a" * 32, pkp, vkp)
 h = ctx.load_circuit(sppc, pkp, int(os.environ.get("SPP_WINDOW", "0")))
-sizes = [1, 2, 4, 8, 16, 17, 32, 64, 128, 256, 512, 1024, 1025, 2048] + ([4096] if cid == 1 else [])
+sizes = [1, 2, 4, 8, 16, 17, 32, 64, 65, 128, 256, 512, 1024, 1025, 2048, 2049] + ([4096] if cid == 1 else [])
 top = max(sizes)
 rows = workload.withdraw_rows(ctx, top) if cid == 1 else workload.audit_rows(ctx, pk["a"], pk["b"], top)
 rng = random.Random(1)
